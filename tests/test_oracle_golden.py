@@ -1,0 +1,164 @@
+"""The oracle (oracle/spatial_clip_oracle.py) against the golden vectors generated from the
+reference's own modules (tests/golden/make_golden.py).  This is what pins parity."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spatial_clip_oracle as O
+
+torch.set_num_threads(4)
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" else z[k]) for k in z.files}
+
+
+def t(x):
+    return x.clone().float()
+
+
+@pytest.mark.parametrize("name", ["blk_d64.npz", "blk_d64_causal.npz", "blk_d128.npz"])
+def test_resblock_fwd_bwd(golden_dir, name):
+    z = load(golden_dir, name)
+    p = {k[2:]: t(v).requires_grad_(True) for k, v in z.items() if k.startswith("p.")}
+    x = t(z["x"]).requires_grad_(True)
+    y = O.resblock(x, p, "", int(z["heads"]), causal=bool(int(z["causal"])))
+    assert torch.allclose(y, z["y"], atol=2e-5, rtol=1e-5)
+    y.backward(z["gy"])
+    assert torch.allclose(x.grad, z["gx"], atol=5e-5, rtol=1e-4)
+    for k, v in p.items():
+        assert torch.allclose(v.grad, z["g." + k], atol=2e-4, rtol=1e-4), k
+
+
+def _cfg_from_json(s):
+    c = json.loads(str(s))
+    v = c["vision_cfg"]
+    tx = c["text_cfg"]
+    return O.ModelCfg(embed_dim=c["embed_dim"],
+                      vision=O.VisionCfg(v["image_size"], v["patch_size"], v["width"], v["layers"],
+                                         v.get("head_width", 64)),
+                      text=O.TextCfg(tx["context_length"], tx["vocab_size"], tx["width"], tx["heads"],
+                                     tx["layers"]), gene=None)
+
+
+def test_clip_tiny_fwd_bwd(golden_dir):
+    z = load(golden_dir, "clip_tiny_fwd_bwd.npz")
+    cfg = _cfg_from_json(z["cfg"])
+    p = {k[2:]: t(v).requires_grad_(True) for k, v in z.items() if k.startswith("p.")}
+    f = O.net_forward(z["images"], z["texts"], p, cfg)
+    assert torch.allclose(f["image_features"], z["image_features"], atol=2e-6)
+    assert torch.allclose(f["text_features"], z["text_features"], atol=2e-6)
+    loss = O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"])
+    assert abs(float(loss) - float(z["loss"])) < 2e-6
+    loss.backward()
+    for k, v in p.items():
+        g = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert torch.allclose(g, z["g." + k], atol=2e-5, rtol=1e-3), k
+
+
+@pytest.mark.parametrize("tag", ["w1_default", "w1_edges", "w1_capped", "w1_noreg_nocap", "w1_bias"])
+def test_losses_w1(golden_dir, tag):
+    z = load(golden_dir, f"loss_{tag}.npz")
+    cap = float(z["cap"])
+    cap = None if cap < 0 else cap
+    bias = torch.tensor(float(z["bias"])) if int(z["has_bias"]) else None
+    for which in ("spatial", "clip"):
+        img = t(z["img"]).requires_grad_(True)
+        txt = t(z["txt"]).requires_grad_(True)
+        s = t(z["scale"]).requires_grad_(True)
+        if which == "spatial":
+            l = O.spatial_loss(img, txt, s, z["ids"], z["ids"], z["nb"], z["alpha"], cap_logit_scale=cap,
+                               temp_reg_weight=float(z["w"]), neighbor_alpha_scale=0.5, logit_bias=bias)
+            pre = "sp"
+        else:
+            l = O.clip_loss(img, txt, s, logit_bias=bias)
+            pre = "cl"
+        assert abs(float(l) - float(z[f"{which}_loss"])) < 2e-6
+        l.backward()
+        assert torch.allclose(img.grad, z[f"{pre}_gimg"], atol=1e-6)
+        assert torch.allclose(txt.grad, z[f"{pre}_gtxt"], atol=1e-6)
+        assert torch.allclose(s.grad, z[f"{pre}_gscale"], atol=1e-6)
+
+
+def test_losses_w2_single_process_equivalent(golden_dir):
+    """Reference ran on 2 gloo ranks with gather_with_grad; the oracle reproduces each rank's loss and
+    (after summing the cross-rank terms = autograd of all_gather) each rank's local-feature grads."""
+    z = load(golden_dir, "loss_w2.npz")
+    W = 2
+    G = z["img"].shape[0]
+    B = G // W
+    for which in ("spatial", "clip"):
+        img = t(z["img"]).requires_grad_(True)
+        txt = t(z["txt"]).requires_grad_(True)
+        s = torch.tensor(float(z["scale"]), requires_grad=True)
+        total = 0
+        rank_losses = []
+        for r in range(W):
+            sl = slice(r * B, (r + 1) * B)
+            if which == "spatial":
+                l = O.spatial_loss(img[sl], txt[sl], s, z["ids"][sl], z["ids"][sl], z["nb"][sl], z["alpha"][sl],
+                                   all_image_features=img, all_text_features=txt,
+                                   all_image_tile_ids=z["ids"], all_text_tile_ids=z["ids"], rank=r)
+            else:
+                l = O.clip_loss(img[sl], txt[sl], s, img, txt, rank=r)
+            rank_losses.append(l)
+            assert abs(float(l) - float(z[f"r{r}_{which}_loss"])) < 2e-6
+            total = total + l
+        # torch.distributed.nn.all_gather backward sums the grads of all ranks' losses
+        total.backward()
+        for r in range(W):
+            sl = slice(r * B, (r + 1) * B)
+            assert torch.allclose(img.grad[sl], z[f"r{r}_{which}_gimg"], atol=1e-6)
+            assert torch.allclose(txt.grad[sl], z[f"r{r}_{which}_gtxt"], atol=1e-6)
+        gs = sum(float(z[f"r{r}_{which}_gscale"]) for r in range(W))
+        assert abs(float(s.grad) - gs) < 1e-5
+
+
+def test_train3_tiny_text(golden_dir):
+    z = load(golden_dir, "train3_tiny_text.npz")
+    cfg = _cfg_from_json(z["cfg"])
+    p0 = {k[3:]: t(v) for k, v in z.items() if k.startswith("p0.")}
+    tr = O.OracleTrainer(cfg, p0, loss="spatial", lr=1e-3, warmup=int(z["warmup"]), total_steps=int(z["total"]))
+    batch = {"images": z["images"], "texts": z["texts"], "image_tile_ids": z["ids"], "text_tile_ids": z["ids"],
+             "neighbor_tile_ids": z["nb"], "neighbor_alphas": z["alpha"]}
+    for step in range(3):
+        out = tr.training_step(batch)
+        assert abs(float(out["loss"]) - float(z["losses"][step])) < 1e-5
+        assert abs(float(out["grad_norm"]) - float(z["grad_norms"][step])) < 1e-4 * max(1, float(z["grad_norms"][step]))
+    for k, v in tr.p.items():
+        assert torch.allclose(v.detach(), z["p3." + k], atol=1e-5, rtol=1e-5), k
+
+
+def test_adamw_matches_torch():
+    torch.manual_seed(0)
+    p = torch.randn(37, 5)
+    q = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([q], lr=3e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 5):
+        g = torch.randn_like(p)
+        q.grad = g.clone()
+        opt.step()
+        O.adamw_step(p, g, m, v, step, 3e-3)
+        assert torch.allclose(p, q.detach(), atol=1e-6)
+
+
+def test_notebook_invariants():
+    """notebooks/test1_loss_test.ipynb cells 1-3: rows of q sum to 1; the main positive of rank r's row i
+    is column r*B+i; neighbour columns resolve only if the neighbour is in the (global) batch."""
+    W, B, K = 3, 4, 3
+    ids = 500 + torch.arange(W * B)
+    nb = torch.full((B, K), -1, dtype=torch.long)
+    al = torch.zeros(B, K)
+    r = 1
+    nb[0, 0], al[0, 0] = ids[0], 0.5          # in global batch (other rank)
+    nb[1, 0], al[1, 0] = 999, 0.7             # absent
+    q_it, q_ti = O.spatial_labels(ids, ids, nb, al, B, r, 1.0)
+    assert torch.allclose(q_it.sum(1), torch.ones(B))
+    assert (q_it.argmax(1) == torch.arange(B) + r * B).all()
+    assert q_it[0, 0] > 0 and abs(float(q_it[0, 0]) - 0.5 / 1.5) < 1e-6
+    assert float(q_it[1].max()) == 1.0 and int((q_it[1] > 0).sum()) == 1
