@@ -1,0 +1,327 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues.  Two operand layouts:
+//   NT : C[M,N] = A[M,K] . B[N,K]^T      (both operands K-contiguous: forward linears and dgrads,
+//                                          the latter against a transposed bf16 weight copy)
+//   TN : C[M,N] = At[K,M]^T . Bt[K,N]     (both operands reduction-major: weight gradients
+//                                          dW = dY^T X straight from the row-major activations,
+//                                          fragments fetched with ds_read_b64_tr_b16)
+// 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles, fp32 accumulate.
+// Register-staged double buffering (global -> VGPR -> swizzled LDS), one barrier per K tile.
+// Edge handling: buffer loads return 0 beyond the operand (outer dims), stores are guarded.
+// The accumulators are produced "swapped" (D = B.A^T) so that every lane owns 4 consecutive columns
+// of C; they are then bounced through LDS once so that global stores / residual loads are full
+// 128..256-byte row segments.
+#include "sc_common.h"
+#include "sc_kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per operand tile
+constexpr int EPI_LD = 68;                         // floats per epilogue row (64 + 4 pad)
+constexpr int LDS_BYTES = 4 * 64 * EPI_LD * 4;     // 69632 >= 4 * TILE_BYTES
+
+struct GemmArgs {
+    const bf16* A;
+    const bf16* B;
+    int M, N, K;
+    int lda, ldb;
+    void* C;
+    int ldc;
+    void* C2;
+    int ldc2;
+    const float* bias;
+    const float* res;
+    int ldres;
+    const bf16* aux;
+    int ldaux;
+    int splitk;
+    int k_per_split;
+    long long slab_stride;
+    int ntm, ntn;
+};
+
+template <int MODE>
+SC_DEVICE void stage_load(u32x4 (&ra)[4], u32x4 (&rb)[4], __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
+                          int lda, int ldb, int k0, int t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = p * 256 + t;
+        if (MODE == SC_GEMM_NT) {
+            const int row = c >> 3, kc = c & 7;
+            ra[p] = sc_buf_load16(rsA, (uint32_t)(row * lda + k0 + kc * 8) * 2u);
+            rb[p] = sc_buf_load16(rsB, (uint32_t)(row * ldb + k0 + kc * 8) * 2u);
+        } else {
+            const int krow = c >> 4, mc = c & 15;
+            ra[p] = sc_buf_load16(rsA, (uint32_t)((k0 + krow) * lda + mc * 8) * 2u);
+            rb[p] = sc_buf_load16(rsB, (uint32_t)((k0 + krow) * ldb + mc * 8) * 2u);
+        }
+    }
+}
+
+template <int MODE>
+SC_DEVICE void stage_store(const u32x4 (&ra)[4], const u32x4 (&rb)[4], char* sA, char* sB, int t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = p * 256 + t;
+        int off;
+        if (MODE == SC_GEMM_NT) {
+            const int row = c >> 3, kc = c & 7;
+            off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+        } else {
+            const int krow = c >> 4, mc = c & 15;
+            const int s = (krow & 3) | (((krow >> 3) & 1) << 2);
+            off = krow * 256 + ((((mc >> 1) ^ s)) << 5) + ((mc & 1) << 4);
+        }
+        *reinterpret_cast<u32x4*>(sA + off) = ra[p];
+        *reinterpret_cast<u32x4*>(sB + off) = rb[p];
+    }
+}
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = idx % g.ntn;
+    idx /= g.ntn;
+    const int tm = idx % g.ntm;
+    const int z = idx / g.ntm;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nt = (kend - kbeg + BK - 1) / BK;
+
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    if (MODE == SC_GEMM_NT) {
+        rsA = sc_make_rsrc(g.A + (size_t)m0 * g.lda, sc_clamp_bytes((uint64_t)max(g.M - m0, 0) * g.lda * 2));
+        rsB = sc_make_rsrc(g.B + (size_t)n0 * g.ldb, sc_clamp_bytes((uint64_t)max(g.N - n0, 0) * g.ldb * 2));
+    } else {
+        // base at (kbeg, m0); everything past the last reduction row is out of range -> 0
+        rsA = sc_make_rsrc(g.A + (size_t)kbeg * g.lda + m0,
+                           sc_clamp_bytes(((uint64_t)(g.K - kbeg) * g.lda - m0) * 2));
+        rsB = sc_make_rsrc(g.B + (size_t)kbeg * g.ldb + n0,
+                           sc_clamp_bytes(((uint64_t)(g.K - kbeg) * g.ldb - n0) * 2));
+    }
+    const int kb = (MODE == SC_GEMM_NT) ? kbeg : 0;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    if (nt > 0) {
+        stage_load<MODE>(ra, rb, rsA, rsB, g.lda, g.ldb, kb, t);
+        stage_store<MODE>(ra, rb, smem, smem + TILE_BYTES, t);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < nt; ++it) {
+        const int cur = it & 1;
+        char* sA = smem + cur * 2 * TILE_BYTES;
+        char* sB = sA + TILE_BYTES;
+        const bool more = (it + 1 < nt);
+        if (more) stage_load<MODE>(ra, rb, rsA, rsB, g.lda, g.ldb, kb + (it + 1) * BK, t);
+
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfr[4];
+            if (MODE == SC_GEMM_NT) {
+                const int sw = (li >> 1) & 7;
+                const int coff = ((kk * 4 + lg) ^ sw) << 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rowa = wm * 64 + i * 16 + li;
+                    const int rowb = wn * 64 + i * 16 + li;
+                    af[i] = *reinterpret_cast<const bf16x8*>(sA + rowa * 128 + coff);
+                    bfr[i] = *reinterpret_cast<const bf16x8*>(sB + rowb * 128 + coff);
+                }
+            } else {
+                const int q = li >> 2, p = li & 3;
+                const int krow = kk * 32 + lg * 8 + q;
+                const int s = q | ((lg & 1) << 2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ca = ((wm * 4 + i) ^ s) << 5;
+                    const int cb = ((wn * 4 + i) ^ s) << 5;
+                    const char* pa = sA + krow * 256 + ca + p * 8;
+                    const char* pb = sB + krow * 256 + cb + p * 8;
+                    af[i] = sc_cat(sc_lds_tr16(pa), sc_lds_tr16(pa + 4 * 256));
+                    bfr[i] = sc_cat(sc_lds_tr16(pb), sc_lds_tr16(pb + 4 * 256));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = sc_mfma16(bfr[j], af[i], acc[i][j]);
+        }
+        if (more) {
+            char* nA = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_store<MODE>(ra, rb, nA, nA + TILE_BYTES, t);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: bounce the wave's 64x64 tile through LDS ----------------
+    float* ep = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(ep + (i * 16 + li) * EPI_LD + j * 16 + lg * 4) = acc[i][j];
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): a wave only reads back its own region
+    __builtin_amdgcn_wave_barrier();
+
+    const int gm0 = m0 + wm * 64, gn0 = n0 + wn * 64;
+    if (EPI == SC_EPI_F32 || EPI == SC_EPI_F32_BIAS_RES) {
+        float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.slab_stride;
+        const int col = (lane & 15) * 4;
+        const int gn = gn0 + col;
+        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (EPI == SC_EPI_F32_BIAS_RES && g.bias && gn < g.N) bv = *reinterpret_cast<const f32x4*>(g.bias + gn);
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+            const int row = ps * 4 + (lane >> 4);
+            const int gm = gm0 + row;
+            if (gm < g.M && gn < g.N) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EPI_LD + col);
+                if (EPI == SC_EPI_F32_BIAS_RES) {
+                    v += bv;
+                    if (g.res) v += *reinterpret_cast<const f32x4*>(g.res + (size_t)gm * g.ldres + gn);
+                }
+                *reinterpret_cast<f32x4*>(C + (size_t)gm * g.ldc + gn) = v;
+            }
+        }
+    } else {
+        bf16* C = reinterpret_cast<bf16*>(g.C);
+        const int col = (lane & 7) * 8;
+        const int gn = gn0 + col;
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+        if ((EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) && g.bias && gn < g.N) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + gn);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias + gn + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+        }
+#pragma unroll 4
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 8 + (lane >> 3);
+            const int gm = gm0 + row;
+            if (gm < g.M && gn < g.N) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * EPI_LD + col);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + row * EPI_LD + col + 4);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
+                if (EPI == SC_EPI_BF16_DGELU) {
+                    const bf16x8 u = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm * g.ldaux + gn);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= sc_gelu_grad((float)u[e]);
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *reinterpret_cast<bf16x8*>(C + (size_t)gm * g.ldc + gn) = o;
+                if (EPI == SC_EPI_GELU_PAIR) {
+                    bf16x8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (bf16)sc_gelu((float)o[e]);
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.C2) + (size_t)gm * g.ldc2 + gn) = h;
+                }
+            }
+        }
+    }
+}
+
+__global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab,
+                                    long long slab_stride, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
+        for (int z = 1; z < nslab; ++z) s += reinterpret_cast<const f32x4*>(slabs + z * slab_stride)[i];
+        reinterpret_cast<f32x4*>(out)[i] = s;
+    }
+}
+
+template <int MODE, int EPI>
+int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    gemm_kernel<MODE, EPI><<<nblocks, 256, LDS_BYTES, st>>>(g);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                            void* C, int ldc, void* C2, int ldc2, const float* bias, const float* res, int ldres,
+                            const void* aux, int ldaux, int splitk, float* slabs, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SC_CHECK(mode == SC_GEMM_NT || mode == SC_GEMM_TN, "sc_gemm_bf16: bad mode %d", mode);
+    SC_CHECK(M > 0 && N > 0 && K > 0, "sc_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
+    SC_CHECK((N % 8) == 0 && (ldc % 4) == 0, "sc_gemm_bf16: N (%d) must be a multiple of 8, ldc (%d) of 4", N, ldc);
+    SC_CHECK((lda % 8) == 0 && (ldb % 8) == 0, "sc_gemm_bf16: lda/ldb (%d,%d) must be multiples of 8", lda, ldb);
+    SC_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
+             "sc_gemm_bf16: operands must be 16-byte aligned");
+    if (mode == SC_GEMM_NT) SC_CHECK((K % BK) == 0, "sc_gemm_bf16: NT needs K %% 64 == 0 (K=%d)", K);
+    if (splitk < 1) splitk = 1;
+    SC_CHECK(splitk == 1 || (epi == SC_EPI_F32 && slabs != nullptr), "sc_gemm_bf16: split-K needs EPI_F32 + slabs");
+    GemmArgs g;
+    g.A = (const bf16*)A; g.B = (const bf16*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
+    g.aux = (const bf16*)aux; g.ldaux = ldaux;
+    g.ntm = (M + BM - 1) / BM; g.ntn = (N + BN - 1) / BN;
+    int ktiles = (K + BK - 1) / BK;
+    if (splitk > ktiles) splitk = ktiles;
+    int tiles_per = (ktiles + splitk - 1) / splitk;
+    splitk = (ktiles + tiles_per - 1) / tiles_per;
+    g.splitk = splitk; g.k_per_split = tiles_per * BK;
+    g.slab_stride = 0;
+    if (splitk > 1) {
+        SC_CHECK(ldc == N, "sc_gemm_bf16: split-K needs a dense C (ldc == N)");
+        g.C = slabs; g.slab_stride = (long long)M * N;
+    }
+    const int nblocks = g.ntm * g.ntn * splitk;
+    int rc = -1;
+#define SC_CASE(MODE, EPI) \
+    if (mode == MODE && epi == EPI) rc = launch<MODE, EPI>(g, nblocks, st);
+    SC_CASE(SC_GEMM_NT, SC_EPI_BF16)
+    SC_CASE(SC_GEMM_NT, SC_EPI_BF16_BIAS)
+    SC_CASE(SC_GEMM_NT, SC_EPI_F32_BIAS_RES)
+    SC_CASE(SC_GEMM_NT, SC_EPI_GELU_PAIR)
+    SC_CASE(SC_GEMM_NT, SC_EPI_BF16_DGELU)
+    SC_CASE(SC_GEMM_NT, SC_EPI_F32)
+    SC_CASE(SC_GEMM_TN, SC_EPI_F32)
+    SC_CASE(SC_GEMM_TN, SC_EPI_BF16)
+#undef SC_CASE
+    SC_CHECK(rc != -1 || false, "sc_gemm_bf16: unsupported (mode=%d, epi=%d)", mode, epi);
+    if (rc != 0) return rc;
+    if (splitk > 1) {
+        const long long n4 = (long long)M * N / 4;
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        reduce_slabs_kernel<<<blocks, 256, 0, st>>>((float*)C, slabs, splitk, g.slab_stride, n4);
+        SC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" long long sc_gemm_slab_floats(int M, int N, int K, int splitk) {
+    int ktiles = (K + BK - 1) / BK;
+    if (splitk < 1) splitk = 1;
+    if (splitk > ktiles) splitk = ktiles;
+    return splitk > 1 ? (long long)splitk * M * N : 0;
+}

@@ -1,0 +1,97 @@
+"""GPU parity of the MFMA GEMM (through the C ABI) against fp32 torch on the same bf16-rounded inputs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import ops
+    return ops
+
+
+def _rand(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def gelu(x):
+    return torch.nn.functional.gelu(x)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 256, 128), (197 * 3, 192, 192), (1000, 576, 192),
+                                   (50, 64, 64), (394, 2304, 768), (300, 768, 3072)])
+def test_nt_plain_and_bias(M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a, b = _rand((M, K), g), _rand((N, K), g, 0.1)
+    bias = torch.randn(N, generator=g)
+    ref = a.float() @ b.float().t()
+    ad, bd = a.cuda(), b.cuda()
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_BF16, ad, bd, out, M=M, N=N, K=K)
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), atol=2e-2, rtol=2e-2)
+    ops.gemm(ops.NT, ops.EPI_BF16_BIAS, ad, bd, out, M=M, N=N, K=K, bias=bias.cuda())
+    torch.testing.assert_close(out.float().cpu(), (ref + bias).to(torch.bfloat16).float(), atol=2e-2, rtol=2e-2)
+    o32 = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_F32, ad, bd, o32, M=M, N=N, K=K)
+    torch.testing.assert_close(o32.cpu(), ref, atol=1e-3, rtol=1e-3)
+
+
+def test_nt_asymmetric_identity():
+    """A = I with an asymmetric B catches transposed / permuted accumulator layouts exactly."""
+    ops = _ops()
+    M = N = K = 128
+    a = torch.eye(M).to(torch.bfloat16)
+    b = (torch.arange(N).view(N, 1) * 3 + torch.arange(K).view(1, K) * 0.5).to(torch.bfloat16)
+    o32 = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_F32, a.cuda(), b.cuda(), o32, M=M, N=N, K=K)
+    assert torch.equal(o32.cpu(), a.float() @ b.float().t())
+
+
+def test_nt_residual_gelu_dgelu():
+    ops = _ops()
+    M, N, K = 333, 192, 256
+    g = torch.Generator().manual_seed(3)
+    a, b = _rand((M, K), g), _rand((N, K), g, 0.1)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = a.float() @ b.float().t()
+    o32 = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, a.cuda(), b.cuda(), o32, M=M, N=N, K=K, bias=bias.cuda(), res=res.cuda())
+    torch.testing.assert_close(o32.cpu(), ref + bias + res, atol=1e-3, rtol=1e-3)
+    u = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    h = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_GELU_PAIR, a.cuda(), b.cuda(), u, M=M, N=N, K=K, bias=bias.cuda(), out2=h)
+    uref = (ref + bias).to(torch.bfloat16)
+    torch.testing.assert_close(u.float().cpu(), uref.float(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(h.float().cpu(), gelu(u.float().cpu()).to(torch.bfloat16).float(), atol=1e-2, rtol=1e-2)
+    aux = _rand((M, N), g)
+    d = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_BF16_DGELU, a.cuda(), b.cuda(), d, M=M, N=N, K=K, aux=aux.cuda())
+    x = aux.float().requires_grad_(True)
+    gelu(x).sum().backward()
+    torch.testing.assert_close(d.float().cpu(), (ref * x.grad).to(torch.bfloat16).float(), atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(128, 128, 64, 1), (192, 192, 197 * 2, 1), (768, 192, 1000, 4),
+                                          (576, 192, 37, 1), (2304, 768, 197 * 8, 8), (512, 20032, 8, 1)])
+def test_tn_wgrad(M, N, K, splitk):
+    ops = _ops()
+    g = torch.Generator().manual_seed(K)
+    at, bt = _rand((K, M), g), _rand((K, N), g)
+    ref = at.float().t() @ bt.float()
+    o32 = torch.full((M, N), -3.0, dtype=torch.float32, device="cuda")
+    ops.gemm(ops.TN, ops.EPI_F32, at.cuda(), bt.cuda(), o32, M=M, N=N, K=K, splitk=splitk)
+    torch.testing.assert_close(o32.cpu(), ref, atol=2e-3 * max(1, K ** 0.5 / 8), rtol=2e-3)
+
+
+def test_tn_asymmetric_exact():
+    ops = _ops()
+    K, M, N = 64, 128, 128
+    at = torch.zeros(K, M)
+    at[torch.arange(K), torch.arange(K) * 2] = 1.0   # At^T picks rows of Bt
+    bt = (torch.arange(K).view(K, 1) * 2.0 + torch.arange(N).view(1, N) * 0.25).to(torch.bfloat16)
+    o32 = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm(ops.TN, ops.EPI_F32, at.to(torch.bfloat16).cuda(), bt.cuda(), o32, M=M, N=N, K=K)
+    assert torch.equal(o32.cpu(), at.t() @ bt.float())
