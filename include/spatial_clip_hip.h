@@ -1,20 +1,142 @@
-/* spatial_clip_hip.h -- C ABI of the MI355X (gfx950) kernels behind the Spatial-CLIP training step.
- * (header grows with the kernels; see bottom of file for the full list)
+/* spatial_clip_hip.h -- C ABI of libspatialclip_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * Spatial-CLIP contrastive training step (Biogod2020/Spatial-Clip, SpatialClipLitModule.training_step).
+ *
+ * The reference has no FFI for this path: its hot path is stock PyTorch ops reached from Python
+ * (SURVEY.md section 8b).  Each entry point below therefore replaces an ATen op *site* of the reference and
+ * cites it (paths relative to the reference repository).  A reference maintainer binds this library with
+ * ctypes; the build's own Python host layer does exactly that (spatial-clip_amd/_lib.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; the callee borrows it for the enqueue only;
+ *   - all workspace / outputs are caller-allocated (no hipMalloc inside: safe under a caching allocator);
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue, they never synchronise;
+ *   - return 0 on success, negative on error; sc_last_error() gives a thread-local message;
+ *   - bf16 tensors are passed as void*, fp32 as float*, tile ids as int64 (long long);
+ *   - "ld*" = row stride in ELEMENTS; matrices are row-major.
  */
 #ifndef SPATIAL_CLIP_HIP_H
 #define SPATIAL_CLIP_HIP_H
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+const char* sc_last_error(void);
+int sc_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------ GEMM
+ * bf16 MFMA GEMM, fp32 accumulate.  Replaces nn.Linear / nn.MultiheadAttention in_proj,out_proj / conv1
+ * (patch embed as GEMM) forward, dgrad and wgrad:  src/open_clip/transformer.py:253,260-264,624-630.
+ *   mode NT: C[M,N] = A[M,K] . B[N,K]^T   (K % 64 == 0)
+ *   mode TN: C[M,N] = At[K,M]^T . Bt[K,N] (weight gradients straight from row-major activations; any K)
+ * epilogues:
+ *   SC_EPI_BF16          C(bf16) = acc
+ *   SC_EPI_BF16_BIAS     C(bf16) = acc + bias[N]
+ *   SC_EPI_F32_BIAS_RES  C(f32)  = acc + bias[N] + res[M,N](f32)        (residual stream update)
+ *   SC_EPI_GELU_PAIR     C(bf16) = u = acc + bias ; C2(bf16) = gelu_erf(u)  (mlp.c_fc + nn.GELU)
+ *   SC_EPI_BF16_DGELU    C(bf16) = acc * gelu'(aux[M,N](bf16))          (c_proj dgrad fused with GELU bwd)
+ *   SC_EPI_F32           C(f32)  = acc ; with splitk > 1 partial slabs go to `slabs` and are reduced into C
+ * N % 8 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.  Outer-dimension edges are handled. */
 enum { SC_GEMM_NT = 0, SC_GEMM_TN = 1 };
 enum { SC_EPI_BF16 = 0, SC_EPI_BF16_BIAS = 1, SC_EPI_F32_BIAS_RES = 2, SC_EPI_GELU_PAIR = 3,
        SC_EPI_BF16_DGELU = 4, SC_EPI_F32 = 5 };
-const char* sc_last_error(void);
 int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                  void* C, int ldc, void* C2, int ldc2, const float* bias, const float* res, int ldres,
                  const void* aux, int ldaux, int splitk, float* slabs, void* stream);
 long long sc_gemm_slab_floats(int M, int N, int K, int splitk);
+
+/* ------------------------------------------------------------------------------------------------ attention
+ * Fused multi-head self-attention on the packed in_proj output qkv[B*L, 3*H*dh] (q | k | v, head h at
+ * columns h*dh): softmax(q k^T / sqrt(dh)) v, fp32 softmax, optional causal mask.  Replaces
+ * nn.MultiheadAttention's SDPA core (src/open_clip/transformer.py:272-287; mask :1080-1086).
+ * out[B*L, H*dh] bf16, lse[B,H,L] fp32 (log-sum-exp of the scaled scores, kept for backward).
+ * sc_attn_bwd writes dqkv[B*L, 3*H*dh] (bf16) and uses delta[B,H,L] as scratch.  L <= 320, dh in {32, 64}. */
+int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dh, int causal, void* stream);
+int sc_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                int B, int L, int H, int dh, int causal, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ LayerNorm
+ * LayerNorm over the last dim of the fp32 residual stream (eps 1e-5; src/open_clip/transformer.py:23-29),
+ * bf16 output feeding the next GEMM; mean/rstd [rows] saved for backward (may be NULL).
+ * Backward: dres = (accumulate ? dres : 0) + LN'(dy); also writes the bf16 copy of the new dres (may be NULL),
+ * dgamma, dbeta and colsum = column sums of the new dres (= bias gradient of the Linear that produced the
+ * residual branch; may be NULL).  ws: sc_layernorm_bwd_ws_floats() floats.  d % 4 == 0, d <= 2048. */
+int sc_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
+                     float* mean, float* rstd, int rows, int d, float eps, void* stream);
+long long sc_layernorm_bwd_ws_floats(int rows, int d);
+int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
+                     const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
+                     long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum, float* ws,
+                     int rows, int d, void* stream);
+
+/* column sums of a bf16 matrix -> fp32 (bias gradients).  ws: sc_colsum_ws_floats() floats. */
+long long sc_colsum_ws_floats(int rows, int n);
+int sc_colsum_bf16(const void* x, long long ld, int rows, int n, float* out, float* ws, void* stream);
+
+/* F.normalize(dim=-1, eps 1e-12) of the embedding heads (src/open_clip/model.py:328,345) and its backward
+ * dx = (dy - y <y,dy>) / max(|x|, eps), emitted in bf16 for the projection dgrad / wgrad GEMMs. */
+int sc_l2norm_fwd(const float* x, float* y, void* y_bf16, float* inv_norm, int rows, int d, void* stream);
+int sc_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* dx_bf16, int rows, int d,
+                  void* stream);
+
+/* fp32 -> bf16 casts of master weights / inputs: row-padded copy and transposed copy (dst[c][r] = src[r][c]). */
+int sc_cast_pad_bf16(const float* src, long long ld_src, void* dst, long long ld_dst, int rows, int cols,
+                     int cols_pad, void* stream);
+int sc_cast_transpose_bf16(const float* src, void* dst, int rows, int cols, long long ld_dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ patch embedding
+ * VisionTransformer._embeds (src/open_clip/transformer.py:783-798): conv1 with kernel = stride = patch is a GEMM
+ * over the im2col'd patches (inner order c,py,px = conv1.weight.view(width,-1)); then class token, positional
+ * embedding and ln_pre, written as the fp32 residual stream x[B*L, d]. */
+int sc_im2col(const float* images, void* patches, int B, int C, int H, int W, int P, long long ld_out, void* stream);
+int sc_embed_ln_fwd(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                    const float* beta, float* x, float* mean, float* rstd, int B, int L, int d, float eps,
+                    void* stream);
+long long sc_embed_ln_bwd_ws_floats(int B, int L, int d);
+int sc_embed_ln_bwd(float* dres, const float* patch_out, const float* cls, const float* pos, const float* mean,
+                    const float* rstd, const float* gamma, void* dpatch_bf16, float* dgamma, float* dbeta,
+                    float* dpos, float* dcls, float* ws, int B, int L, int d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ contrastive head
+ * ClipLoss (src/open_clip/loss.py:91-155, local_loss layout) and SpatialLoss
+ * (src/models/components/losses.py:44-124) on the device.  z[2][B][G] holds the cosine similarities
+ * (z[0] = image_features . all_text^T, z[1] = text_features . all_image^T), produced with sc_sgemm_f32.
+ * Soft labels are sparse: lab_col/lab_w[2][B][nlab] ((column, weight) pairs, column -1 = unused); they come from
+ * sc_onehot_labels (ClipLoss: arange(B)+B*rank, loss.py:94-96) or sc_neighbor_join (SpatialLoss label loop,
+ * losses.py:91-111: id -> LAST index, alpha*scale <= 0 skipped, L1-normalised).
+ * loss_out[4] = {loss, gap, CE_image, CE_text}; cap_logit_scale <= 0 disables the STE cap; temp_reg_weight 0
+ * disables the gap^2 term.  Backward overwrites z with dL/dz and returns d logit_scale (of the *exponentiated*
+ * scale) and d logit_bias; feature grads are then two sc_sgemm_f32 calls per direction. */
+int sc_sgemm_f32(const float* A, long long sam, long long sak, const float* B, long long sbn, long long sbk,
+                 float* C, long long ldc, int M, int N, int K, int accumulate, void* stream);
+int sc_neighbor_join(const long long* all_image_tile_ids, const long long* all_text_tile_ids,
+                     const long long* neighbor_tile_ids, const float* neighbor_alphas, int B, int G, int K, int rank,
+                     float neighbor_alpha_scale, int* lab_col, float* lab_w, void* stream);
+int sc_onehot_labels(int B, int rank, int* lab_col, float* lab_w, void* stream);
+int sc_contrastive_loss_fwd(const float* z, int B, int G, const float* logit_scale, float cap_logit_scale,
+                            const float* logit_bias, const int* lab_col, const float* lab_w, int nlab,
+                            float temp_reg_weight, float* rowstats, float* loss_out, void* stream);
+int sc_contrastive_loss_bwd(float* z_inout, int B, int G, const float* logit_scale, float cap_logit_scale,
+                            const float* logit_bias, const int* lab_col, const float* lab_w, int nlab,
+                            float temp_reg_weight, const float* rowstats, const float* loss_out,
+                            const float* grad_out, float* rowgrad, float* dscale, float* dbias, void* stream);
+/* RecallAtK (src/models/components/metrics.py:22-36) on the local [B,B] block of z[0]: hits3 += {R@1,R@5,R@10}. */
+int sc_recall_hits(const float* z_image_rows, int G, int B, int col0, int* hits3, void* stream);
+/* logit_scale.exp() (src/models/components/spatial_clip_net.py:51) and its backward dx = dy * y * mult. */
+int sc_exp_scalar(const float* x, float* y, void* stream);
+int sc_exp_scalar_bwd(const float* y, const float* dy, float* dx, float mult, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ optimiser
+ * clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (src/models/spatial_clip_module.py:138-158,
+ * configs/optimizer/adamw.yaml, configs/trainer/default.yaml:19).  grad_scale = 1/world_size folds DDP's
+ * gradient mean.  sc_grad_norm writes norm_clip_out[2] = {|g|*grad_scale, min(1, max_norm/(norm+1e-6))};
+ * ws: 1024 doubles.  sc_adamw_step reads the clip coefficient from norm_clip[1] (NULL = no clipping). */
+int sc_grad_norm(const float* grads, long long n, float grad_scale, float max_norm, double* ws, float* norm_clip_out,
+                 void* stream);
+int sc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  const float* norm_clip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
-#endif
+#endif /* SPATIAL_CLIP_HIP_H */

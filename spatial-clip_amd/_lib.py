@@ -1,20 +1,50 @@
-"""ctypes binding of libspatialclip_hip.so (the C ABI declared in include/spatial_clip_hip.h).
+"""ctypes binding of libspatialclip_hip.so, generated from the public header include/spatial_clip_hip.h.
 
 No torch types cross the boundary: tensors are passed as raw device pointers + explicit sizes and the
-HIP stream as a ``void*``.  Loading fails loudly -- there is no fallback path."""
+HIP stream as a ``void*``.  Loading fails loudly -- there is no CPU / eager fallback path."""
 from __future__ import annotations
 
 import ctypes
 import os
+import re
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
+from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspatialclip_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "spatial_clip_hip.h")
 _lib = None
 
 
 class SpatialClipHipError(RuntimeError):
     pass
+
+
+def _ctype(decl: str):
+    decl = decl.strip()
+    if "*" in decl:
+        return c_void_p
+    if decl.startswith("long long"):
+        return c_longlong
+    if decl.startswith("float"):
+        return c_float
+    if decl.startswith("int"):
+        return c_int
+    raise ValueError(f"unsupported C type in header: {decl!r}")
+
+
+def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object]]]:
+    """{name: (restype, [argtypes])} for every function the header declares."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"enum\s*\{.*?\};", " ", src, flags=re.S)
+    out: Dict[str, Tuple[object, List[object]]] = {}
+    for m in re.finditer(r"(const char\*|long long|int)\s+(sc_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = {"const char*": c_char_p, "long long": c_longlong, "int": c_int}[ret]
+        argtypes = [] if args in ("", "void") else [_ctype(a) for a in args.split(",")]
+        out[name] = (restype, argtypes)
+    return out
 
 
 def lib() -> ctypes.CDLL:
@@ -24,28 +54,13 @@ def lib() -> ctypes.CDLL:
             raise SpatialClipHipError(
                 f"{LIB_PATH} is missing: build it with `python spatial-clip_amd/build.py` "
                 "(or __graft_entry__.build()). There is no CPU fallback.")
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.sc_last_error.restype = c_char_p
-        _declare(_lib)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(l, name)   # AttributeError if the library lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = l
     return _lib
-
-
-I, F, P, LL = c_int, c_float, c_void_p, c_longlong
-
-# name -> argtypes; every function returns int (0 = ok) unless listed in _RESTYPES
-SIGNATURES = {
-    "sc_abi_version": [],
-    "sc_gemm_bf16": [I, I, P, I, P, I, I, I, I, P, I, P, I, P, P, I, P, I, I, P, P],
-    "sc_gemm_slab_floats": [I, I, I, I],
-}
-_RESTYPES = {"sc_gemm_slab_floats": c_longlong}
-
-
-def _declare(l: ctypes.CDLL) -> None:
-    for name, args in SIGNATURES.items():
-        fn = getattr(l, name)
-        fn.argtypes = args
-        fn.restype = _RESTYPES.get(name, c_int)
 
 
 def check(rc: int, what: str) -> None:

@@ -1,0 +1,369 @@
+// Multi-head self-attention for short sequences (L <= 320: ViT 197/257 tokens, CLIP text 77) on gfx950.
+// One workgroup (4 waves) owns one (batch, head).  The whole K and V of that head sit in LDS (<= 80 KiB at
+// L=320, dh=64) in ONE swizzled image each that serves both row reads (ds_read_b128) and transposed reads
+// (ds_read_b64_tr_b16), so there is no multi-block online softmax and no [L,L] matrix in HBM.
+//
+// All products keep the query on the MFMA *column* (lane & 15), i.e. they are computed transposed:
+//   S^T[key][q]  = K . Q^T          (A = K rows from LDS,   B = Q rows from registers)
+//   O^T[d][q]    = V^T . P^T        (A = V by tr-read,       B = P^T = the S^T accumulators, in place)
+// so the softmax statistics of a query live in the same lanes as its accumulators (no cross-lane moves
+// except a 4-lane max/sum), and the probabilities feed the second MFMA without touching LDS.
+// k-slot convention for "accumulator as operand": for a 32-key block, element j of lane group g is
+// key 4g+j (j<4) or 16+4g+(j-4) (j>=4) -- both operands use the same order.
+//
+// Backward = two kernels with the same structure:
+//   dq kernel : per query tile, loop key blocks : S^T, dP^T = V.dO^T, dS^T, dQ^T += K^T . dS^T  (+ delta)
+//   dkv kernel: per key tile,   loop query blocks: S = Q.K^T, dP = dO.V^T, dV^T += dO^T.P, dK^T += Q^T.dS
+// Reference semantics: nn.MultiheadAttention via src/open_clip/transformer.py:253,272-287 (scale 1/sqrt(dh)
+// on q.k, fp32 softmax, optional additive causal mask :1080-1086).
+#include "sc_common.h"
+#include "sc_kernels.h"
+
+namespace {
+
+constexpr int MAXL = 320;
+
+template <int DH>
+struct Img {
+    // image of [rows][DH] bf16, row = DH*2 bytes, 16-byte chunks XOR-swizzled so that b128 row reads and
+    // tr_b16 reads are both bank-conflict free (derivation in DESIGN.md).
+    static constexpr int ROWB = DH * 2;
+    static SC_DEVICE int swz(int row) { return DH == 64 ? (((row >> 1) & 3) << 1) : (((row >> 2) & 1) << 1); }
+    static SC_DEVICE int off(int row, int chunk16) { return row * ROWB + ((chunk16 ^ swz(row)) << 4); }
+};
+
+// cooperative load of rows [0,L) x DH of one head into an LDS image, zero-filling rows [L, Lp)
+template <int DH>
+SC_DEVICE void load_image(char* img, const bf16* src, long long row_stride, int L, int Lp, int t) {
+    constexpr int CH = DH / 8;
+    for (int c = t; c < Lp * CH; c += 256) {
+        const int row = c / CH, ch = c % CH;
+        u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+        if (row < L) v = *reinterpret_cast<const u32x4*>(src + (long long)row * row_stride + ch * 8);
+        *reinterpret_cast<u32x4*>(img + Img<DH>::off(row, ch)) = v;
+    }
+}
+
+// A/B fragment by row read: lane (g,i) gets img[row0+i][ks*32 + 8g .. +7]
+template <int DH>
+SC_DEVICE bf16x8 frag_row(const char* img, int row0, int ks, int li, int lg) {
+    return *reinterpret_cast<const bf16x8*>(img + Img<DH>::off(row0 + li, ks * 4 + lg));
+}
+
+// transposed fragment over a 32-row block starting at row0 for the 16 columns [c0, c0+16):
+// lane (g,i) gets img[row0 + slot(g,j)][c0 + i], j = 0..7
+template <int DH>
+SC_DEVICE bf16x8 frag_tr(const char* img, int row0, int c0, int li, int lg) {
+    const int q = li >> 2, p = li & 3;
+    const int r1 = row0 + 4 * lg + q, r2 = r1 + 16;
+    const int ch = (c0 >> 3) + (p >> 1);
+    const bf16x4 lo = sc_lds_tr16(img + Img<DH>::off(r1, ch) + ((p & 1) << 3));
+    const bf16x4 hi = sc_lds_tr16(img + Img<DH>::off(r2, ch) + ((p & 1) << 3));
+    return sc_cat(lo, hi);
+}
+
+SC_DEVICE bf16x8 pack8(f32x4 a, f32x4 b) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = (bf16)a[e]; r[4 + e] = (bf16)b[e]; }
+    return r;
+}
+
+SC_DEVICE float quad_max(float v) {  // over the 4 lanes that share lane&15
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+SC_DEVICE float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int DH, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                          float* __restrict__ lse, int L, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = DH / 32, DT = DH / 16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int d = H * DH;
+    const long long rs = 3LL * d;
+    const bf16* base = qkv + (long long)b * L * rs + h * DH;
+    const int Lp = (L + 31) & ~31;
+    char* Kimg = smem;
+    char* Vimg = smem + Lp * DH * 2;
+    load_image<DH>(Kimg, base + d, rs, L, Lp, t);
+    load_image<DH>(Vimg, base + 2 * d, rs, L, Lp, t);
+    __syncthreads();
+    const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
+    const int nqt = (L + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + li;           // this lane's query (B-operand column)
+        const int qc = min(q, L - 1);
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long long)qc * rs + ks * 32 + lg * 8);
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float m = -1e30f, lsum = 0.f;
+        const int kend = CAUSAL ? min(Lp, ((qt * 16 + 15) / 32 + 1) * 32) : Lp;
+        for (int k0 = 0; k0 < kend; k0 += 32) {
+            f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = sc_mfma16(frag_row<DH>(Kimg, k0, ks, li, lg), qf[ks], s0);
+                s1 = sc_mfma16(frag_row<DH>(Kimg, k0 + 16, ks, li, lg), qf[ks], s1);
+            }
+            float mx = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ka = k0 + 4 * lg + r, kb = ka + 16;
+                if (ka >= L || (CAUSAL && ka > q)) s0[r] = -1e30f;
+                if (kb >= L || (CAUSAL && kb > q)) s1[r] = -1e30f;
+                mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+            }
+            mx = quad_max(mx);
+            const float mn = fmaxf(m, mx);
+            const float alpha = exp2f((m - mn) * c2);
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = exp2f((s0[r] - mn) * c2);
+                s1[r] = exp2f((s1[r] - mn) * c2);
+                ps += s0[r] + s1[r];
+            }
+            lsum = lsum * alpha + ps;
+            const bf16x8 pf = pack8(s0, s1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[dt] *= alpha;
+                o[dt] = sc_mfma16(frag_tr<DH>(Vimg, k0, dt * 16, li, lg), pf, o[dt]);
+            }
+        }
+        lsum = quad_sum(lsum);
+        const float inv = 1.0f / lsum;
+        if (q < L) {
+            bf16* orow = out + ((long long)b * L + q) * d + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                *reinterpret_cast<u32x2*>(orow + dt * 16 + lg * 4) =
+                    sc_pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            if (lg == 0) lse[((long long)b * H + h) * L + q] = m * scale + __logf(lsum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward: dQ (+ delta)
+template <int DH, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, bf16* __restrict__ dqkv, int L,
+                                                             int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = DH / 32, DT = DH / 16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int d = H * DH;
+    const long long rs = 3LL * d;
+    const bf16* base = qkv + (long long)b * L * rs + h * DH;
+    const int Lp = (L + 31) & ~31;
+    char* Kimg = smem;
+    char* Vimg = smem + Lp * DH * 2;
+    load_image<DH>(Kimg, base + d, rs, L, Lp, t);
+    load_image<DH>(Vimg, base + 2 * d, rs, L, Lp, t);
+    __syncthreads();
+    const float c2 = scale * 1.4426950408889634f;
+    const int nqt = (L + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + li;
+        const int qc = min(q, L - 1);
+        bf16x8 qf[KS], dof[KS];
+        float dl = 0.f;
+        const bf16* orow = out + ((long long)b * L + qc) * d + h * DH;
+        const bf16* grow = dout + ((long long)b * L + qc) * d + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long long)qc * rs + ks * 32 + lg * 8);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(grow + ks * 32 + lg * 8);
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + ks * 32 + lg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[e];
+        }
+        dl = quad_sum(dl);
+        const float nl2 = -lse[((long long)b * H + h) * L + qc] * 1.4426950408889634f;
+        if (q < L && lg == 0) delta[((long long)b * H + h) * L + q] = dl;
+        f32x4 dq[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int kend = CAUSAL ? min(Lp, ((qt * 16 + 15) / 32 + 1) * 32) : Lp;
+        for (int k0 = 0; k0 < kend; k0 += 32) {
+            f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = sc_mfma16(frag_row<DH>(Kimg, k0, ks, li, lg), qf[ks], s0);
+                s1 = sc_mfma16(frag_row<DH>(Kimg, k0 + 16, ks, li, lg), qf[ks], s1);
+                p0 = sc_mfma16(frag_row<DH>(Vimg, k0, ks, li, lg), dof[ks], p0);
+                p1 = sc_mfma16(frag_row<DH>(Vimg, k0 + 16, ks, li, lg), dof[ks], p1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ka = k0 + 4 * lg + r, kb = ka + 16;
+                const float pa = (ka >= L || (CAUSAL && ka > q)) ? 0.f : exp2f(s0[r] * c2 + nl2);
+                const float pb = (kb >= L || (CAUSAL && kb > q)) ? 0.f : exp2f(s1[r] * c2 + nl2);
+                s0[r] = pa * (p0[r] - dl);
+                s1[r] = pb * (p1[r] - dl);
+            }
+            const bf16x8 dsf = pack8(s0, s1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                dq[dt] = sc_mfma16(frag_tr<DH>(Kimg, k0, dt * 16, li, lg), dsf, dq[dt]);
+        }
+        if (q < L) {
+            bf16* drow = dqkv + ((long long)b * L + q) * rs + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                *reinterpret_cast<u32x2*>(drow + dt * 16 + lg * 4) =
+                    sc_pack4(dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward: dK, dV
+template <int DH, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv,
+                                                              const bf16* __restrict__ dout,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                              int L, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = DH / 32, DT = DH / 16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int d = H * DH;
+    const long long rs = 3LL * d;
+    const bf16* base = qkv + (long long)b * L * rs + h * DH;
+    const int Lp = (L + 31) & ~31;
+    char* Qimg = smem;
+    char* Gimg = smem + Lp * DH * 2;
+    float* slse = reinterpret_cast<float*>(smem + 2 * Lp * DH * 2);
+    float* sdel = slse + Lp;
+    load_image<DH>(Qimg, base, rs, L, Lp, t);
+    load_image<DH>(Gimg, dout + (long long)b * L * d + h * DH, d, L, Lp, t);
+    for (int i = t; i < Lp; i += 256) {
+        slse[i] = i < L ? -lse[((long long)b * H + h) * L + i] * 1.4426950408889634f : 0.f;
+        sdel[i] = i < L ? delta[((long long)b * H + h) * L + i] : 0.f;
+    }
+    __syncthreads();
+    const float c2 = scale * 1.4426950408889634f;
+    const int nkt = (L + 15) >> 4;
+    for (int kt = wave; kt < nkt; kt += 4) {
+        const int key = kt * 16 + li;  // this lane's key (B-operand column)
+        const int kc = min(key, L - 1);
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(base + d + (long long)kc * rs + ks * 32 + lg * 8);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * d + (long long)kc * rs + ks * 32 + lg * 8);
+        }
+        f32x4 dk[DT], dv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int qbeg = CAUSAL ? ((kt * 16) / 32) * 32 : 0;
+        for (int q0 = qbeg; q0 < Lp; q0 += 32) {
+            // S[q][key], dP[q][key]: rows = queries 4g+r (+16), col = key
+            f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = sc_mfma16(frag_row<DH>(Qimg, q0, ks, li, lg), kf[ks], s0);
+                s1 = sc_mfma16(frag_row<DH>(Qimg, q0 + 16, ks, li, lg), kf[ks], s1);
+                p0 = sc_mfma16(frag_row<DH>(Gimg, q0, ks, li, lg), vf[ks], p0);
+                p1 = sc_mfma16(frag_row<DH>(Gimg, q0 + 16, ks, li, lg), vf[ks], p1);
+            }
+            f32x4 pr0, pr1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qa = q0 + 4 * lg + r, qb = qa + 16;
+                const float pa = (qa >= L || key >= L || (CAUSAL && key > qa)) ? 0.f : exp2f(s0[r] * c2 + slse[qa]);
+                const float pb = (qb >= L || key >= L || (CAUSAL && key > qb)) ? 0.f : exp2f(s1[r] * c2 + slse[qb]);
+                pr0[r] = pa;
+                pr1[r] = pb;
+                s0[r] = pa * (p0[r] - sdel[qa]);
+                s1[r] = pb * (p1[r] - sdel[qb]);
+            }
+            const bf16x8 pf = pack8(pr0, pr1), dsf = pack8(s0, s1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = sc_mfma16(frag_tr<DH>(Gimg, q0, dt * 16, li, lg), pf, dv[dt]);
+                dk[dt] = sc_mfma16(frag_tr<DH>(Qimg, q0, dt * 16, li, lg), dsf, dk[dt]);
+            }
+        }
+        if (key < L) {
+            bf16* drow = dqkv + ((long long)b * L + key) * rs + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                *reinterpret_cast<u32x2*>(drow + d + dt * 16 + lg * 4) =
+                    sc_pack4(dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale);
+                *reinterpret_cast<u32x2*>(drow + 2 * d + dt * 16 + lg * 4) =
+                    sc_pack4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+            }
+        }
+    }
+}
+
+template <typename K>
+void set_lds(K kern, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bytes);
+}
+
+}  // namespace
+
+#define SC_ATTN_DISPATCH(KERNEL, ...)                                                         \
+    do {                                                                                      \
+        if (dh == 64 && !causal) { set_lds(KERNEL<64, false>, lds); KERNEL<64, false><<<B * H, 256, lds, st>>>(__VA_ARGS__); } \
+        else if (dh == 64 && causal) { set_lds(KERNEL<64, true>, lds); KERNEL<64, true><<<B * H, 256, lds, st>>>(__VA_ARGS__); } \
+        else if (dh == 32 && !causal) { set_lds(KERNEL<32, false>, lds); KERNEL<32, false><<<B * H, 256, lds, st>>>(__VA_ARGS__); } \
+        else { set_lds(KERNEL<32, true>, lds); KERNEL<32, true><<<B * H, 256, lds, st>>>(__VA_ARGS__); } \
+    } while (0)
+
+static int attn_check(const char* who, int B, int L, int H, int dh) {
+    SC_CHECK(B > 0 && H > 0 && L > 0 && L <= MAXL, "%s: need 0 < L <= %d (L=%d), B=%d H=%d", who, MAXL, L, B, H);
+    SC_CHECK(dh == 64 || dh == 32, "%s: head dim must be 32 or 64 (got %d)", who, dh);
+    return 0;
+}
+
+extern "C" int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dh, int causal,
+                           void* stream) {
+    if (attn_check("sc_attn_fwd", B, L, H, dh)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int Lp = (L + 31) & ~31;
+    const size_t lds = (size_t)2 * Lp * dh * 2;
+    const float scale = 1.0f / sqrtf((float)dh);
+    SC_ATTN_DISPATCH(attn_fwd_kernel, (const bf16*)qkv, (bf16*)out, lse, L, H, scale);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                           void* dqkv, int B, int L, int H, int dh, int causal, void* stream) {
+    if (attn_check("sc_attn_bwd", B, L, H, dh)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int Lp = (L + 31) & ~31;
+    const float scale = 1.0f / sqrtf((float)dh);
+    {
+        const size_t lds = (size_t)2 * Lp * dh * 2;
+        SC_ATTN_DISPATCH(attn_bwd_dq_kernel, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta,
+                         (bf16*)dqkv, L, H, scale);
+        SC_LAUNCH_CHECK();
+    }
+    {
+        const size_t lds = (size_t)2 * Lp * dh * 2 + (size_t)2 * Lp * 4;
+        SC_ATTN_DISPATCH(attn_bwd_dkv_kernel, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, L, H,
+                         scale);
+        SC_LAUNCH_CHECK();
+    }
+    return 0;
+}

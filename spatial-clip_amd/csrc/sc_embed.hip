@@ -1,0 +1,238 @@
+// Patch embedding glue of the ViT tower (reference: VisionTransformer._embeds, src/open_clip/transformer.py:783-798).
+//   sc_im2col        : NCHW fp32 images -> [B*G*G, 3*P*P] bf16 patch matrix (inner order c,py,px = conv1.weight)
+//   sc_embed_ln_fwd  : tokens = [class_embedding ; patch GEMM out] + positional_embedding, then ln_pre,
+//                      written as the fp32 residual stream
+//   sc_embed_ln_bwd  : LN backward of ln_pre; emits d(token) fp32 (in place), the packed bf16 d(patch out)
+//                      for the conv wgrad GEMM, and dgamma/dbeta
+//   sc_batch_sum     : d(positional_embedding)[t] = sum_b d(token)[b,t]  (row 0 is also d(class_embedding))
+#include "sc_common.h"
+#include "sc_kernels.h"
+
+namespace {
+
+constexpr int MAXV = 8;
+SC_DEVICE f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+SC_DEVICE void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__global__ void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int C, int H, int W, int P,
+                              long long ld_out) {
+    // one thread per (b, gy, gx, c, py): copies P pixels
+    const int G_h = H / P, G_w = W / P;
+    const long long total = (long long)B * G_h * G_w * C * P;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int gx = (int)(r % G_w); r /= G_w;
+        const int py = (int)(r % P); r /= P;
+        const int c = (int)(r % C); r /= C;
+        const int gy = (int)(r % G_h); r /= G_h;
+        const int b = (int)r;
+        const float* src = img + (((long long)b * C + c) * H + gy * P + py) * W + gx * P;
+        bf16* dst = out + ((long long)(b * G_h + gy) * G_w + gx) * ld_out + (c * P + py) * P;
+        if ((P & 3) == 0 && (W & 3) == 0) {
+            for (int x = 0; x < P; x += 4) {
+                const f32x4 v = ld4(src + x);
+                bf16x4 o;
+                o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+                *reinterpret_cast<bf16x4*>(dst + x) = o;
+            }
+        } else {
+            for (int x = 0; x < P; ++x) dst[x] = (bf16)src[x];
+        }
+    }
+}
+
+// one wave per token row
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ x,
+                                                           float* __restrict__ mean, float* __restrict__ rstd, int B,
+                                                           int L, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int b = row / L, tkn = row - b * L;
+    const float* src = tkn == 0 ? cls : patch + ((long long)b * (L - 1) + (tkn - 1)) * d;
+    const float* pr = pos + (long long)tkn * d;
+    const int nv = d >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = i * 64 + lane;
+        if (e < nv) {
+            v[i] = ld4(src + e * 4) + ld4(pr + e * 4);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mu = sc_wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = i * 64 + lane;
+        if (e < nv) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float u = v[i][c] - mu; q += u * u; }
+        }
+    }
+    const float rs = rsqrtf(sc_wave_sum(q) / (float)d + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = i * 64 + lane;
+        if (e < nv) {
+            const f32x4 g = ld4(gamma + e * 4), bb = ld4(beta + e * 4);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (v[i][c] - mu) * rs * g[c] + bb[c];
+            st4(x + (long long)row * d + e * 4, o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(float* __restrict__ dres, const float* __restrict__ patch,
+                                                           const float* __restrict__ cls, const float* __restrict__ pos,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, bf16* __restrict__ dpatch,
+                                                           float* __restrict__ partial, int B, int L, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = d >> 2;
+    const int rows = B * L;
+    f32x4 ag[MAXV], ab[MAXV], gm[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        ag[i] = ab[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int e = i * 64 + lane;
+        gm[i] = e < nv ? ld4(gamma + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int b = row / L, tkn = row - b * L;
+        const float* src = tkn == 0 ? cls : patch + ((long long)b * (L - 1) + (tkn - 1)) * d;
+        const float* pr = pos + (long long)tkn * d;
+        const float mu = mean[row], rs = rstd[row];
+        float* dr = dres + (long long)row * d;
+        f32x4 g[MAXV], xh[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = i * 64 + lane;
+            if (e < nv) {
+                const f32x4 dyv = ld4(dr + e * 4);
+                const f32x4 xv = ld4(src + e * 4) + ld4(pr + e * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    xh[i][c] = (xv[c] - mu) * rs;
+                    g[i][c] = dyv[c] * gm[i][c];
+                    s1 += g[i][c];
+                    s2 += g[i][c] * xh[i][c];
+                    ag[i][c] += dyv[c] * xh[i][c];
+                    ab[i][c] += dyv[c];
+                }
+            }
+        }
+        s1 = sc_wave_sum(s1) / (float)d;
+        s2 = sc_wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = i * 64 + lane;
+            if (e < nv) {
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = rs * (g[i][c] - s1 - xh[i][c] * s2);
+                st4(dr + e * 4, o);
+                if (tkn > 0) {
+                    bf16x4 ob;
+                    ob[0] = (bf16)o[0]; ob[1] = (bf16)o[1]; ob[2] = (bf16)o[2]; ob[3] = (bf16)o[3];
+                    *reinterpret_cast<bf16x4*>(dpatch + ((long long)b * (L - 1) + (tkn - 1)) * d + e * 4) = ob;
+                }
+            }
+        }
+    }
+    float* sm = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = i * 64 + lane;
+        if (e < nv) {
+            st4(sm + (wave * 2 + 0) * d + e * 4, ag[i]);
+            st4(sm + (wave * 2 + 1) * d + e * 4, ab[i]);
+        }
+    }
+    __syncthreads();
+    float* pout = partial + (long long)blockIdx.x * 2 * d;
+    for (int e = threadIdx.x; e < 2 * d; e += 256) pout[e] = sm[e] + sm[2 * d + e] + sm[4 * d + e] + sm[6 * d + e];
+}
+
+__global__ void colvec2_finalize_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ o0,
+                                        float* __restrict__ o1) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * d) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * 2 * d + e];
+    if (e < d) o0[e] = s; else o1[e - d] = s;
+}
+
+// out[i] = sum_b x[b*n + i], i < n (n = L*d), float4 lanes
+__global__ void batch_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) s += reinterpret_cast<const f32x4*>(x)[(long long)b * n4 + i];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+}  // namespace
+
+extern "C" int sc_im2col(const float* images, void* patches, int B, int C, int H, int W, int P, long long ld_out,
+                         void* stream) {
+    SC_CHECK(B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0, "sc_im2col: bad shape B=%d C=%d H=%d W=%d P=%d", B, C,
+             H, W, P);
+    SC_CHECK(ld_out >= (long long)C * P * P && (ld_out % 4) == 0, "sc_im2col: ld_out too small / unaligned");
+    const long long total = (long long)B * (H / P) * (W / P) * C * P;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    im2col_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(images, (bf16*)patches, B, C, H, W, P, ld_out);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_embed_ln_fwd(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                               const float* beta, float* x, float* mean, float* rstd, int B, int L, int d, float eps,
+                               void* stream) {
+    SC_CHECK(B > 0 && L > 1 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_embed_ln_fwd: bad shape B=%d L=%d d=%d", B, L, d);
+    embed_ln_fwd_kernel<<<(B * L + 3) / 4, 256, 0, (hipStream_t)stream>>>(patch_out, cls, pos, gamma, beta, x, mean,
+                                                                        rstd, B, L, d, eps);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long long sc_embed_ln_bwd_ws_floats(int B, int L, int d) {
+    int nblk = (B * L + 3) / 4;
+    if (nblk > 1024) nblk = 1024;
+    return (long long)nblk * 2 * d;
+}
+
+extern "C" int sc_embed_ln_bwd(float* dres, const float* patch_out, const float* cls, const float* pos,
+                               const float* mean, const float* rstd, const float* gamma, void* dpatch_bf16,
+                               float* dgamma, float* dbeta, float* dpos, float* dcls, float* ws, int B, int L, int d,
+                               void* stream) {
+    SC_CHECK(B > 0 && L > 1 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_embed_ln_bwd: bad shape B=%d L=%d d=%d", B, L, d);
+    hipStream_t st = (hipStream_t)stream;
+    int nblk = (B * L + 3) / 4;
+    if (nblk > 1024) nblk = 1024;
+    const size_t lds = (size_t)4 * 2 * d * sizeof(float);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    embed_ln_bwd_kernel<<<nblk, 256, lds, st>>>(dres, patch_out, cls, pos, mean, rstd, gamma, (bf16*)dpatch_bf16, ws, B,
+                                                L, d);
+    SC_LAUNCH_CHECK();
+    colvec2_finalize_kernel<<<(2 * d + 255) / 256, 256, 0, st>>>(ws, nblk, d, dgamma, dbeta);
+    SC_LAUNCH_CHECK();
+    const long long n4 = (long long)L * d / 4;
+    batch_sum_kernel<<<(int)((n4 + 255) / 256), 256, 0, st>>>(dres, dpos, B, n4);
+    SC_LAUNCH_CHECK();
+    // d(class_embedding) = d(token row 0) summed over the batch = dpos[0]
+    (void)hipMemcpyAsync(dcls, dpos, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return 0;
+}

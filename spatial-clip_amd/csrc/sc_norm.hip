@@ -1,0 +1,349 @@
+// HBM-bound row kernels of the ViT tower: LayerNorm fwd/bwd on the fp32 residual stream (bf16 out for
+// the next GEMM), L2-normalise fwd/bwd of the embedding heads, column sums (bias grads), casts.
+// One 64-lane wave owns one row; every access is a 16-byte (fp32x4) or 8-byte (bf16x4) vector.
+#include "sc_common.h"
+#include "sc_kernels.h"
+
+namespace {
+
+constexpr int MAXV = 8;  // float4 slots per lane -> d <= 2048
+
+SC_DEVICE f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+SC_DEVICE void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+SC_DEVICE f32x4 ldbf4(const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+SC_DEVICE void stbf4(bf16* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// ------------------------------------------------------------------ LayerNorm forward
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     bf16* __restrict__ y, long long ldy, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long long)row * ldx;
+    const int nv = d >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = i * 64 + lane;
+        if (e < nv) {
+            v[i] = ld4(xr + e * 4);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mu = sc_wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = i * 64 + lane;
+        if (e < nv) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float t = v[i][c] - mu; q += t * t; }
+        }
+    }
+    const float rs = rsqrtf(sc_wave_sum(q) / (float)d + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+    bf16* yr = y + (long long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = i * 64 + lane;
+        if (e < nv) {
+            const f32x4 g = ld4(gamma + e * 4), b = ld4(beta + e * 4);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (v[i][c] - mu) * rs * g[c] + b[c];
+            stbf4(yr + e * 4, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+// dres_new = (accumulate ? dres : 0) + LNbwd(dy); also emits the bf16 copy of dres_new (the A operand of
+// the next dgrad / wgrad GEMMs) and per-block partials of dgamma, dbeta and colsum(dres_new).
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long long lddy,
+                                                     const float* __restrict__ x, long long ldx,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, float* __restrict__ dres,
+                                                     long long lddres, bf16* __restrict__ dres_bf, long long lddbf,
+                                                     float* __restrict__ partial, int rows, int d, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = d >> 2;
+    f32x4 ag[MAXV], ab[MAXV], ac[MAXV], gm[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        ag[i] = ab[i] = ac[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int e = i * 64 + lane;
+        gm[i] = e < nv ? ld4(gamma + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const bf16* dyr = dy + (long long)row * lddy;
+        const float* xr = x + (long long)row * ldx;
+        f32x4 g[MAXV], xh[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = i * 64 + lane;
+            if (e < nv) {
+                const f32x4 dyv = ldbf4(dyr + e * 4);
+                const f32x4 xv = ld4(xr + e * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    xh[i][c] = (xv[c] - mu) * rs;
+                    g[i][c] = dyv[c] * gm[i][c];
+                    s1 += g[i][c];
+                    s2 += g[i][c] * xh[i][c];
+                    ag[i][c] += dyv[c] * xh[i][c];
+                    ab[i][c] += dyv[c];
+                }
+            }
+        }
+        s1 = sc_wave_sum(s1) / (float)d;
+        s2 = sc_wave_sum(s2) / (float)d;
+        float* dr = dres + (long long)row * lddres;
+        bf16* db = dres_bf ? dres_bf + (long long)row * lddbf : nullptr;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int e = i * 64 + lane;
+            if (e < nv) {
+                f32x4 o = accumulate ? ld4(dr + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    o[c] += rs * (g[i][c] - s1 - xh[i][c] * s2);
+                    ac[i][c] += o[c];
+                }
+                st4(dr + e * 4, o);
+                if (db) stbf4(db + e * 4, o);
+            }
+        }
+    }
+    // block reduce of the 3 column vectors: smem[wave][3][d]
+    float* sm = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int e = i * 64 + lane;
+        if (e < nv) {
+            st4(sm + (wave * 3 + 0) * d + e * 4, ag[i]);
+            st4(sm + (wave * 3 + 1) * d + e * 4, ab[i]);
+            st4(sm + (wave * 3 + 2) * d + e * 4, ac[i]);
+        }
+    }
+    __syncthreads();
+    float* pout = partial + (long long)blockIdx.x * 3 * d;
+    for (int e = threadIdx.x; e < 3 * d; e += 256) {
+        pout[e] = sm[e] + sm[3 * d + e] + sm[6 * d + e] + sm[9 * d + e];
+    }
+}
+
+// out_k[c] = sum_b partial[b][k][c], k = 0..nvec-1 ; outputs may be null
+__global__ void colvec_finalize_kernel(const float* __restrict__ partial, int nblk, int nvec, int d,
+                                       float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nvec * d) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * nvec * d + e];
+    const int k = e / d, c = e - k * d;
+    float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
+    if (o) o[c] = s;
+}
+
+// ------------------------------------------------------------------ column sums of a bf16 matrix
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long long ld, int rows, int n,
+                                                     float* __restrict__ partial) {
+    // block = 64 column-quads x 4 row lanes; grid.x over column chunks of 256, grid.y over row slices
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + cq) * 4;
+    __shared__ f32x4 sm[4][64];
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (col < n) {
+        for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) acc += ldbf4(x + (long long)r * ld + col);
+    }
+    sm[rl][cq] = acc;
+    __syncthreads();
+    if (rl == 0 && col < n) {
+        const f32x4 s = sm[0][cq] + sm[1][cq] + sm[2][cq] + sm[3][cq];
+        st4(partial + (long long)blockIdx.y * n + col, s);
+    }
+}
+
+// ------------------------------------------------------------------ L2 normalise (F.normalize, eps 1e-12)
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         bf16* __restrict__ ybf, float* __restrict__ inv, int rows,
+                                                         int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long long)row * d;
+    float s = 0.f;
+    for (int e = lane; e < d; e += 64) s += xr[e] * xr[e];
+    const float iv = 1.0f / fmaxf(sqrtf(sc_wave_sum(s)), 1e-12f);
+    if (lane == 0 && inv) inv[row] = iv;
+    for (int e = lane; e < d; e += 64) {
+        const float o = xr[e] * iv;
+        y[(long long)row * d + e] = o;
+        if (ybf) ybf[(long long)row * d + e] = (bf16)o;
+    }
+}
+
+// dx = (dy - y * <y,dy>) * inv   (y = normalised output); written as bf16 for the dgrad/wgrad GEMMs
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ inv, bf16* __restrict__ dx,
+                                                         int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* yr = y + (long long)row * d;
+    const float* gr = dy + (long long)row * d;
+    float s = 0.f;
+    for (int e = lane; e < d; e += 64) s += yr[e] * gr[e];
+    s = sc_wave_sum(s);
+    const float iv = inv[row];
+    for (int e = lane; e < d; e += 64) dx[(long long)row * d + e] = (bf16)((gr[e] - yr[e] * s) * iv);
+}
+
+// ------------------------------------------------------------------ casts
+__global__ void cast_pad_kernel(const float* __restrict__ src, long long lds_, bf16* __restrict__ dst, long long ldd,
+                                int rows, int cols, int cols_pad) {
+    const long long nq = (long long)rows * (cols_pad >> 2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nq;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / (cols_pad >> 2));
+        const int c = (int)(i - (long long)r * (cols_pad >> 2)) * 4;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < cols) {
+            v = ld4(src + r * lds_ + c);
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (c + k < cols) v[k] = src[r * lds_ + c + k];
+        }
+        stbf4(dst + r * ldd + c, v);
+    }
+}
+
+// dst[c][r] = bf16(src[r][c]) through a 64x64 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                             int rows, int cols, long long ldd) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(long long)c * ldd + r] = (bf16)tile[tx][i];
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, void* y,
+                                long long ldy, float* mean, float* rstd, int rows, int d, float eps, void* stream) {
+    SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_fwd: bad shape rows=%d d=%d", rows, d);
+    SC_CHECK((ldx % 4) == 0 && (ldy % 4) == 0, "sc_layernorm_fwd: row strides must be multiples of 4");
+    ln_fwd_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows,
+                                                                  d, eps);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
+    int nblk = (rows + 3) / 4;
+    if (nblk > 1024) nblk = 1024;
+    return (long long)nblk * 3 * d;
+}
+
+extern "C" int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
+                                const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
+                                long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum,
+                                float* ws, int rows, int d, void* stream) {
+    SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_bwd: bad shape rows=%d d=%d", rows, d);
+    SC_CHECK(ws != nullptr, "sc_layernorm_bwd: workspace required");
+    int nblk = (rows + 3) / 4;
+    if (nblk > 1024) nblk = 1024;
+    const size_t lds = (size_t)4 * 3 * d * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    ln_bwd_kernel<<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres,
+                                          (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate);
+    SC_LAUNCH_CHECK();
+    colvec_finalize_kernel<<<(3 * d + 255) / 256, 256, 0, st>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long long sc_colsum_ws_floats(int rows, int n) {
+    int ny = (rows + 63) / 64;
+    if (ny > 256) ny = 256;
+    if (ny < 1) ny = 1;
+    return (long long)ny * n;
+}
+
+extern "C" int sc_colsum_bf16(const void* x, long long ld, int rows, int n, float* out, float* ws, void* stream) {
+    SC_CHECK(rows > 0 && n > 0 && (n % 4) == 0 && (ld % 4) == 0, "sc_colsum_bf16: bad shape rows=%d n=%d", rows, n);
+    int ny = (rows + 63) / 64;
+    if (ny > 256) ny = 256;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((n + 255) / 256, ny);
+    colsum_kernel<<<grid, 256, 0, st>>>((const bf16*)x, ld, rows, n, ws);
+    SC_LAUNCH_CHECK();
+    colvec_finalize_kernel<<<(n + 255) / 256, 256, 0, st>>>(ws, ny, 1, n, out, nullptr, nullptr);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_l2norm_fwd(const float* x, float* y, void* y_bf16, float* inv_norm, int rows, int d, void* stream) {
+    SC_CHECK(rows > 0 && d > 0, "sc_l2norm_fwd: bad shape");
+    l2norm_fwd_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, y, (bf16*)y_bf16, inv_norm, rows, d);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* dx_bf16, int rows, int d,
+                             void* stream) {
+    SC_CHECK(rows > 0 && d > 0, "sc_l2norm_bwd: bad shape");
+    l2norm_bwd_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(dy, y, inv_norm, (bf16*)dx_bf16, rows, d);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_cast_pad_bf16(const float* src, long long ld_src, void* dst, long long ld_dst, int rows, int cols,
+                                int cols_pad, void* stream) {
+    SC_CHECK(rows > 0 && cols > 0 && cols_pad >= cols && (cols_pad % 4) == 0 && (ld_dst % 4) == 0,
+             "sc_cast_pad_bf16: bad shape rows=%d cols=%d pad=%d", rows, cols, cols_pad);
+    SC_CHECK((ld_src % 4) == 0 || cols_pad == cols || true, "unreachable");
+    const long long nq = (long long)rows * (cols_pad / 4);
+    int blocks = (int)((nq + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    // vector loads need 16-byte aligned rows; fall back to scalar gather inside the kernel otherwise
+    cast_pad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(src, ld_src, (bf16*)dst, ld_dst, rows,
+                                                             (ld_src % 4) == 0 ? cols : 0 * cols + cols, cols_pad);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_cast_transpose_bf16(const float* src, void* dst, int rows, int cols, long long ld_dst, void* stream) {
+    SC_CHECK(rows > 0 && cols > 0 && ld_dst >= rows, "sc_cast_transpose_bf16: bad shape");
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    cast_transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, (bf16*)dst, rows, cols, ld_dst);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

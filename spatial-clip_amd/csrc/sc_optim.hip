@@ -1,0 +1,99 @@
+// Optimiser step on flat fp32 buffers: global grad-norm (for clip_grad_norm_ 1.0), fused AdamW with the clip
+// coefficient and the 1/world_size gradient averaging applied on the fly, no host synchronisation.
+//   reference: torch.optim.AdamW(lr, betas=(0.9,0.98), eps=1e-6, weight_decay=0.1) over ALL parameters
+//   (src/models/spatial_clip_module.py:138-158, configs/optimizer/adamw.yaml) + Lightning gradient_clip_val 1.0
+//   (configs/trainer/default.yaml:19 == torch.nn.utils.clip_grad_norm_).
+#include "sc_common.h"
+#include "sc_kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n,
+                                                            double* __restrict__ partial) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        acc += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long long i = n4 << 2; i < n; ++i) acc += (double)x[i] * x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// out[0] = sqrt(sum)*gscale (the norm of the averaged gradient), out[1] = clip coefficient
+__global__ void sumsq_final_kernel(const double* __restrict__ partial, int nblk, float gscale, float max_norm,
+                                   float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(s) * gscale;
+        out[0] = norm;
+        out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long long n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, float gscale, const float* __restrict__ normclip) {
+    const float gs = gscale * (normclip ? normclip[1] : 1.0f);
+    const long long n4 = n >> 2;
+    const float decay = 1.0f - lr * wd;
+    const float step = lr / bc1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ge = gg[c] * gs;
+            pp[c] *= decay;
+            mm[c] = b1 * mm[c] + (1.0f - b1) * ge;
+            vv[c] = b2 * vv[c] + (1.0f - b2) * ge * ge;
+            const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
+            pp[c] -= step * (mm[c] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp;
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_grad_norm(const float* grads, long long n, float grad_scale, float max_norm, double* ws,
+                            float* norm_clip_out, void* stream) {
+    SC_CHECK(n > 0 && ws && norm_clip_out, "sc_grad_norm: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = 1024;
+    sumsq_partial_kernel<<<nblk, 256, 0, st>>>(grads, n, ws);
+    SC_LAUNCH_CHECK();
+    sumsq_final_kernel<<<1, 64, 0, st>>>(ws, nblk, grad_scale, max_norm, norm_clip_out);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             const float* norm_clip, void* stream) {
+    SC_CHECK(n > 0 && (n % 4) == 0 && step >= 1, "sc_adamw_step: n must be a positive multiple of 4, step >= 1");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    long long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    adamw_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                                                           weight_decay, bc1, bc2s, grad_scale, norm_clip);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

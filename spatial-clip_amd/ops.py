@@ -66,3 +66,189 @@ def gemm(mode: int, epi: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tenso
                         _ptr(aux), aux.stride(0) if aux is not None else 0, splitk, _ptr(slabs), _stream())
     check(rc, "sc_gemm_bf16")
     return out
+
+
+# ------------------------------------------------------------------------------------------ workspace
+_ws_cache = {}
+
+
+def workspace(nfloat: int, device, tag: str = "ws", dtype=torch.float32) -> torch.Tensor:
+    key = (device.index, tag, dtype)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nfloat:
+        buf = torch.empty(max(int(nfloat), 1024), dtype=dtype, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_fwd(qkv: torch.Tensor, B: int, L: int, H: int, dh: int, causal: bool = False,
+             out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None):
+    _req(qkv, torch.bfloat16, "qkv")
+    if out is None:
+        out = torch.empty((B * L, H * dh), dtype=torch.bfloat16, device=qkv.device)
+    if lse is None:
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().sc_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, L, H, dh, int(causal), _stream()),
+          "sc_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B: int, L: int, H: int, dh: int, causal: bool = False,
+             dqkv: Optional[torch.Tensor] = None, delta: Optional[torch.Tensor] = None):
+    for t_, n in ((qkv, "qkv"), (out, "out"), (dout, "dout")):
+        _req(t_, torch.bfloat16, n)
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if delta is None:
+        delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().sc_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                 dqkv.data_ptr(), B, L, H, dh, int(causal), _stream()), "sc_attn_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------ norms
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows: int, d: int, ldx: Optional[int] = None,
+                  ldy: Optional[int] = None, eps: float = 1e-5):
+    _req(x, torch.float32, "x"); _req(y, torch.bfloat16, "y")
+    check(_lib.lib().sc_layernorm_fwd(x.data_ptr(), ldx if ldx is not None else d, gamma.data_ptr(), beta.data_ptr(),
+                                      y.data_ptr(), ldy if ldy is not None else d, _ptr(mean), _ptr(rstd), rows, d, eps,
+                                      _stream()), "sc_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, colsum, rows: int, d: int, *,
+                  accumulate: bool, lddy=None, ldx=None, lddres=None, lddbf=None):
+    _req(dy, torch.bfloat16, "dy"); _req(x, torch.float32, "x"); _req(dres, torch.float32, "dres")
+    l = _lib.lib()
+    ws = workspace(l.sc_layernorm_bwd_ws_floats(rows, d), dy.device, "ln")
+    check(l.sc_layernorm_bwd(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
+                             gamma.data_ptr(), dres.data_ptr(), lddres or d, _ptr(dres_bf16), lddbf or d,
+                             int(accumulate), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(colsum), ws.data_ptr(), rows, d,
+                             _stream()), "sc_layernorm_bwd")
+
+
+def colsum_bf16(x, rows: int, n: int, out, ld: Optional[int] = None):
+    _req(x, torch.bfloat16, "x"); _req(out, torch.float32, "out")
+    l = _lib.lib()
+    ws = workspace(l.sc_colsum_ws_floats(rows, n), x.device, "colsum")
+    check(l.sc_colsum_bf16(x.data_ptr(), ld or x.stride(0), rows, n, out.data_ptr(), ws.data_ptr(), _stream()),
+          "sc_colsum_bf16")
+    return out
+
+
+def l2norm_fwd(x, y, y_bf16, inv, rows: int, d: int):
+    check(_lib.lib().sc_l2norm_fwd(x.data_ptr(), y.data_ptr(), _ptr(y_bf16), _ptr(inv), rows, d, _stream()),
+          "sc_l2norm_fwd")
+    return y
+
+
+def l2norm_bwd(dy, y, inv, dx_bf16, rows: int, d: int):
+    check(_lib.lib().sc_l2norm_bwd(dy.data_ptr(), y.data_ptr(), inv.data_ptr(), dx_bf16.data_ptr(), rows, d, _stream()),
+          "sc_l2norm_bwd")
+    return dx_bf16
+
+
+def cast_pad_bf16(src, dst, rows: int, cols: int, cols_pad: int, ld_src=None, ld_dst=None):
+    _req(src, torch.float32, "src"); _req(dst, torch.bfloat16, "dst")
+    check(_lib.lib().sc_cast_pad_bf16(src.data_ptr(), ld_src or cols, dst.data_ptr(), ld_dst or cols_pad, rows, cols,
+                                      cols_pad, _stream()), "sc_cast_pad_bf16")
+    return dst
+
+
+def cast_transpose_bf16(src, dst, rows: int, cols: int, ld_dst=None):
+    _req(src, torch.float32, "src"); _req(dst, torch.bfloat16, "dst")
+    check(_lib.lib().sc_cast_transpose_bf16(src.data_ptr(), dst.data_ptr(), rows, cols, ld_dst or rows, _stream()),
+          "sc_cast_transpose_bf16")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------ patch embedding
+def im2col(images, patches, P: int, ld_out: Optional[int] = None):
+    _req(images, torch.float32, "images"); _req(patches, torch.bfloat16, "patches")
+    B, C, H, W = images.shape
+    if not images.is_contiguous():
+        raise ValueError("images must be contiguous NCHW")
+    check(_lib.lib().sc_im2col(images.data_ptr(), patches.data_ptr(), B, C, H, W, P, ld_out or patches.stride(0),
+                               _stream()), "sc_im2col")
+    return patches
+
+
+def embed_ln_fwd(patch_out, cls, pos, gamma, beta, x, mean, rstd, B: int, L: int, d: int, eps: float = 1e-5):
+    check(_lib.lib().sc_embed_ln_fwd(patch_out.data_ptr(), cls.data_ptr(), pos.data_ptr(), gamma.data_ptr(),
+                                     beta.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, L, d, eps,
+                                     _stream()), "sc_embed_ln_fwd")
+    return x
+
+
+def embed_ln_bwd(dres, patch_out, cls, pos, mean, rstd, gamma, dpatch_bf16, dgamma, dbeta, dpos, dcls, B, L, d):
+    l = _lib.lib()
+    ws = workspace(l.sc_embed_ln_bwd_ws_floats(B, L, d), dres.device, "embed")
+    check(l.sc_embed_ln_bwd(dres.data_ptr(), patch_out.data_ptr(), cls.data_ptr(), pos.data_ptr(), mean.data_ptr(),
+                            rstd.data_ptr(), gamma.data_ptr(), dpatch_bf16.data_ptr(), dgamma.data_ptr(),
+                            dbeta.data_ptr(), dpos.data_ptr(), dcls.data_ptr(), ws.data_ptr(), B, L, d, _stream()),
+          "sc_embed_ln_bwd")
+
+
+# ------------------------------------------------------------------------------------------ contrastive head
+def sgemm(a, sam, sak, b, sbn, sbk, c, ldc, M, N, K, accumulate=False):
+    check(_lib.lib().sc_sgemm_f32(a.data_ptr(), sam, sak, b.data_ptr(), sbn, sbk, c.data_ptr(), ldc, M, N, K,
+                                  int(accumulate), _stream()), "sc_sgemm_f32")
+    return c
+
+
+def neighbor_join(all_img_ids, all_txt_ids, nbr_ids, nbr_alpha, B, G, K, rank, alpha_scale, lab_col, lab_w):
+    for t_, n in ((all_img_ids, "all_image_tile_ids"), (all_txt_ids, "all_text_tile_ids"), (nbr_ids, "neighbor_tile_ids")):
+        _req(t_, torch.int64, n)
+    _req(nbr_alpha, torch.float32, "neighbor_alphas")
+    check(_lib.lib().sc_neighbor_join(all_img_ids.data_ptr(), all_txt_ids.data_ptr(), nbr_ids.data_ptr(),
+                                      nbr_alpha.data_ptr(), B, G, K, rank, float(alpha_scale), lab_col.data_ptr(),
+                                      lab_w.data_ptr(), _stream()), "sc_neighbor_join")
+
+
+def onehot_labels(B, rank, lab_col, lab_w):
+    check(_lib.lib().sc_onehot_labels(B, rank, lab_col.data_ptr(), lab_w.data_ptr(), _stream()), "sc_onehot_labels")
+
+
+def contrastive_loss_fwd(z, B, G, scale, cap, bias, lab_col, lab_w, nlab, w, rowstats, loss_out):
+    check(_lib.lib().sc_contrastive_loss_fwd(z.data_ptr(), B, G, scale.data_ptr(), float(cap), _ptr(bias),
+                                             lab_col.data_ptr(), lab_w.data_ptr(), nlab, float(w),
+                                             rowstats.data_ptr(), loss_out.data_ptr(), _stream()),
+          "sc_contrastive_loss_fwd")
+
+
+def contrastive_loss_bwd(z, B, G, scale, cap, bias, lab_col, lab_w, nlab, w, rowstats, loss_out, grad_out, rowgrad,
+                         dscale, dbias):
+    check(_lib.lib().sc_contrastive_loss_bwd(z.data_ptr(), B, G, scale.data_ptr(), float(cap), _ptr(bias),
+                                             lab_col.data_ptr(), lab_w.data_ptr(), nlab, float(w),
+                                             rowstats.data_ptr(), loss_out.data_ptr(), _ptr(grad_out),
+                                             rowgrad.data_ptr(), _ptr(dscale), _ptr(dbias), _stream()),
+          "sc_contrastive_loss_bwd")
+
+
+def recall_hits(z_img_rows, G, B, col0, hits3):
+    check(_lib.lib().sc_recall_hits(z_img_rows.data_ptr(), G, B, col0, hits3.data_ptr(), _stream()), "sc_recall_hits")
+
+
+def exp_scalar(x, y):
+    check(_lib.lib().sc_exp_scalar(x.data_ptr(), y.data_ptr(), _stream()), "sc_exp_scalar")
+    return y
+
+
+def exp_scalar_bwd(y, dy, dx, mult: float = 1.0):
+    check(_lib.lib().sc_exp_scalar_bwd(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), float(mult), _stream()),
+          "sc_exp_scalar_bwd")
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def grad_norm(grads, n, grad_scale, max_norm, out2):
+    ws = workspace(1024, grads.device, "gn", torch.float64)
+    check(_lib.lib().sc_grad_norm(grads.data_ptr(), n, float(grad_scale), float(max_norm), ws.data_ptr(),
+                                  out2.data_ptr(), _stream()), "sc_grad_norm")
+    return out2
+
+
+def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_scale, norm_clip):
+    check(_lib.lib().sc_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(lr), float(beta1),
+                                   float(beta2), float(eps), float(wd), int(step), float(grad_scale), _ptr(norm_clip),
+                                   _stream()), "sc_adamw_step")

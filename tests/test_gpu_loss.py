@@ -1,0 +1,111 @@
+"""GPU parity of the fused contrastive head against the golden vectors (reference outputs) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spatial_clip_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _head():
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import contrastive
+    return contrastive
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.mark.parametrize("tag", ["w1_default", "w1_edges", "w1_capped", "w1_noreg_nocap", "w1_bias"])
+def test_losses_w1_vs_reference_golden(golden_dir, tag):
+    C = _head()
+    z = load(golden_dir, f"loss_{tag}.npz")
+    cap = float(z["cap"]); cap = None if cap < 0 else cap
+    bias = torch.tensor(float(z["bias"])).cuda() if int(z["has_bias"]) else None
+    img, txt = z["img"].cuda(), z["txt"].cuda()
+    s = z["scale"].float().cuda()
+    for which in ("spatial", "clip"):
+        if which == "spatial":
+            res = C.contrastive_forward_backward(
+                img, txt, s, mode="spatial", image_tile_ids=z["ids"].cuda(), text_tile_ids=z["ids"].cuda(),
+                neighbor_tile_ids=z["nb"].cuda(), neighbor_alphas=z["alpha"].cuda(), cap_logit_scale=cap,
+                temp_reg_weight=float(z["w"]), neighbor_alpha_scale=0.5, logit_bias=bias)
+            pre = "sp"
+        else:
+            res = C.contrastive_forward_backward(img, txt, s, mode="clip", logit_bias=bias)
+            pre = "cl"
+        assert abs(float(res["loss"]) - float(z[f"{which}_loss"])) < 5e-6
+        torch.testing.assert_close(res["d_image"].cpu(), z[f"{pre}_gimg"], atol=2e-6, rtol=1e-4)
+        torch.testing.assert_close(res["d_text"].cpu(), z[f"{pre}_gtxt"], atol=2e-6, rtol=1e-4)
+        assert abs(float(res["d_scale"]) - float(z[f"{pre}_gscale"])) < 2e-6
+
+
+def test_losses_w2_emulated_ranks(golden_dir):
+    """Each rank's loss / local grads for a 2-rank global batch, emulated on one GPU: the cross-rank
+    d(all_features) terms are summed by hand exactly as the reduce-scatter would."""
+    C = _head()
+    z = load(golden_dir, "loss_w2.npz")
+    W, G = 2, z["img"].shape[0]
+    B = G // W
+    img, txt, ids = z["img"].cuda(), z["txt"].cuda(), z["ids"].cuda()
+    s = torch.tensor(float(z["scale"])).cuda()
+    for which in ("spatial", "clip"):
+        outs = []
+        for r in range(W):
+            sl = slice(r * B, (r + 1) * B)
+            kw = dict(all_image=img, all_text=txt, rank=r)
+            if which == "spatial":
+                kw.update(mode="spatial", image_tile_ids=ids[sl], text_tile_ids=ids[sl], all_image_tile_ids=ids,
+                          all_text_tile_ids=ids, neighbor_tile_ids=z["nb"][sl].cuda(),
+                          neighbor_alphas=z["alpha"][sl].cuda(), cap_logit_scale=40.0, temp_reg_weight=0.05,
+                          neighbor_alpha_scale=0.5)
+            else:
+                kw.update(mode="clip")
+            res = C.contrastive_forward_backward(img[sl].contiguous(), txt[sl].contiguous(), s, **kw)
+            assert abs(float(res["loss"]) - float(z[f"r{r}_{which}_loss"])) < 5e-6
+            outs.append(res)
+        for r in range(W):
+            sl = slice(r * B, (r + 1) * B)
+            gi = outs[r]["d_image"] + sum(o["d_all_image"][sl] for o in outs)
+            gt = outs[r]["d_text"] + sum(o["d_all_text"][sl] for o in outs)
+            torch.testing.assert_close(gi.cpu(), z[f"r{r}_{which}_gimg"], atol=2e-6, rtol=1e-4)
+            torch.testing.assert_close(gt.cpu(), z[f"r{r}_{which}_gtxt"], atol=2e-6, rtol=1e-4)
+            assert abs(float(outs[r]["d_scale"]) - float(z[f"r{r}_{which}_gscale"])) < 2e-6
+
+
+def test_spatial_loss_large_vs_oracle():
+    C = _head()
+    g = torch.Generator().manual_seed(0)
+    B, G, D, K = 64, 256, 128, 8
+    img = torch.nn.functional.normalize(torch.randn(G, D, generator=g), dim=-1)
+    txt = torch.nn.functional.normalize(img + 0.5 * torch.randn(G, D, generator=g), dim=-1)
+    ids = 1000 + torch.randperm(G, generator=g)
+    nb = ids[torch.randint(0, G, (B, K), generator=g)]
+    nb[:, -1] = -1
+    al = torch.rand(B, K, generator=g); al[:, -1] = 0
+    r = 2
+    sl = slice(r * B, (r + 1) * B)
+    il = img[sl].clone().requires_grad_(True); tl = txt[sl].clone().requires_grad_(True)
+    s = torch.tensor(30.0, requires_grad=True)
+    ai = img.clone().requires_grad_(True); at = txt.clone().requires_grad_(True)
+    loss = O.spatial_loss(il, tl, s, ids[sl], ids[sl], nb, al, ai, at, ids, ids, rank=r)
+    loss.backward()
+    res = C.contrastive_forward_backward(img[sl].contiguous().cuda(), txt[sl].contiguous().cuda(), s.detach().cuda(),
+                                         mode="spatial", all_image=img.cuda(), all_text=txt.cuda(), rank=r,
+                                         image_tile_ids=ids[sl].cuda(), text_tile_ids=ids[sl].cuda(),
+                                         all_image_tile_ids=ids.cuda(), all_text_tile_ids=ids.cuda(),
+                                         neighbor_tile_ids=nb.cuda(), neighbor_alphas=al.cuda(), cap_logit_scale=40.0,
+                                         temp_reg_weight=0.05, neighbor_alpha_scale=0.5)
+    assert abs(float(res["loss"]) - float(loss)) < 1e-5
+    torch.testing.assert_close(res["d_image"].cpu(), il.grad, atol=1e-6, rtol=1e-3)
+    torch.testing.assert_close(res["d_all_text"].cpu(), at.grad, atol=1e-6, rtol=1e-3)
+    torch.testing.assert_close(res["d_all_image"].cpu(), ai.grad, atol=1e-6, rtol=1e-3)
+    # recall hits vs metrics.py semantics
+    logits = (il.detach() @ tl.detach().t()) * 30.0
+    for k, h in zip((1, 5, 10), res["recall_hits"].cpu().tolist()):
+        assert h == O.recall_at_k(logits, torch.arange(B), k)[0]

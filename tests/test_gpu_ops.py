@@ -1,0 +1,196 @@
+"""GPU parity of the non-GEMM kernels (through the C ABI) against the CPU oracle's maths."""
+import math
+
+import pytest
+import torch
+
+from oracle import spatial_clip_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import ops
+    return ops
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def ref_attn(qkv, B, L, H, dh, causal):
+    d = H * dh
+    q, k, v = qkv.float().view(B, L, 3 * d).split(d, dim=-1)
+    q = q.view(B, L, H, dh).transpose(1, 2)
+    k = k.view(B, L, H, dh).transpose(1, 2)
+    v = v.view(B, L, H, dh).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    a = torch.softmax(s, -1)
+    return (a @ v).transpose(1, 2).reshape(B * L, d), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,L,H,dh,causal", [(2, 197, 3, 64, False), (3, 17, 2, 32, False), (2, 13, 2, 32, True),
+                                             (2, 77, 8, 64, True), (1, 257, 2, 64, False), (4, 16, 2, 32, True),
+                                             (2, 64, 1, 64, False)])
+def test_attention_fwd_bwd(B, L, H, dh, causal):
+    ops = _ops()
+    g = torch.Generator().manual_seed(L + dh)
+    d = H * dh
+    qkv = bf(torch.randn(B * L, 3 * d, generator=g))
+    dout = bf(torch.randn(B * L, d, generator=g))
+    x = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = ref_attn(x, B, L, H, dh, causal)
+    o_ref.backward(dout.float())
+    out, lse = ops.attn_fwd(qkv.cuda(), B, L, H, dh, causal)
+    torch.testing.assert_close(out.float().cpu(), o_ref.detach(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(lse.cpu(), lse_ref.detach(), atol=2e-3, rtol=1e-3)
+    dqkv = ops.attn_bwd(qkv.cuda(), out, dout.cuda(), lse, B, L, H, dh, causal)
+    torch.testing.assert_close(dqkv.float().cpu(), x.grad, atol=4e-2, rtol=4e-2)
+
+
+@pytest.mark.parametrize("rows,d", [(50, 768), (197 * 2, 192), (33, 64), (7, 1024)])
+def test_layernorm_fwd_bwd(rows, d):
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, d, generator=g) * 2 + 0.5
+    gamma = torch.randn(d, generator=g)
+    beta = torch.randn(d, generator=g)
+    dy = bf(torch.randn(rows, d, generator=g))
+    dres0 = torch.randn(rows, d, generator=g)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    y_ref = O.layer_norm(xr, gr, br)
+    y_ref.backward(dy.float())
+    dev = "cuda"
+    y = torch.empty(rows, d, dtype=torch.bfloat16, device=dev)
+    mean = torch.empty(rows, device=dev)
+    rstd = torch.empty(rows, device=dev)
+    ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), y, mean, rstd, rows, d)
+    torch.testing.assert_close(y.float().cpu(), y_ref.detach(), atol=3e-2, rtol=2e-2)
+    for acc in (False, True):
+        dres = dres0.clone().cuda()
+        dbf = torch.empty(rows, d, dtype=torch.bfloat16, device=dev)
+        dg = torch.empty(d, device=dev); db = torch.empty(d, device=dev); cs = torch.empty(d, device=dev)
+        ops.layernorm_bwd(dy.cuda(), x.cuda(), mean, rstd, gamma.cuda(), dres, dbf, dg, db, cs, rows, d, accumulate=acc)
+        want = xr.grad + (dres0 if acc else 0)
+        torch.testing.assert_close(dres.cpu(), want, atol=2e-4, rtol=1e-4)
+        torch.testing.assert_close(dbf.float().cpu(), want, atol=3e-2, rtol=2e-2)
+        torch.testing.assert_close(dg.cpu(), gr.grad, atol=1e-3, rtol=1e-4)
+        torch.testing.assert_close(db.cpu(), br.grad, atol=1e-3, rtol=1e-4)
+        torch.testing.assert_close(cs.cpu(), want.sum(0), atol=2e-3, rtol=1e-4)
+
+
+def test_layernorm_strided_rows():
+    """ln_post acts on the CLS rows only: row stride L*d."""
+    ops = _ops()
+    B, L, d = 5, 7, 64
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B * L, d, generator=g)
+    gamma = torch.randn(d, generator=g); beta = torch.randn(d, generator=g)
+    y = torch.empty(B, d, dtype=torch.bfloat16, device="cuda")
+    mean = torch.empty(B, device="cuda"); rstd = torch.empty(B, device="cuda")
+    ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), y, mean, rstd, B, d, ldx=L * d)
+    ref = O.layer_norm(x.view(B, L, d)[:, 0], gamma, beta)
+    torch.testing.assert_close(y.float().cpu(), ref, atol=3e-2, rtol=2e-2)
+
+
+def test_colsum_l2norm_casts():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    x = bf(torch.randn(1000, 192, generator=g))
+    out = torch.empty(192, device="cuda")
+    ops.colsum_bf16(x.cuda(), 1000, 192, out)
+    torch.testing.assert_close(out.cpu(), x.float().sum(0), atol=1e-3, rtol=1e-4)
+    f = torch.randn(37, 512, generator=g)
+    y = torch.empty(37, 512, device="cuda"); ybf = torch.empty(37, 512, dtype=torch.bfloat16, device="cuda")
+    inv = torch.empty(37, device="cuda")
+    ops.l2norm_fwd(f.cuda(), y, ybf, inv, 37, 512)
+    fr = f.clone().requires_grad_(True)
+    yr = torch.nn.functional.normalize(fr, dim=-1)
+    torch.testing.assert_close(y.cpu(), yr.detach(), atol=1e-6, rtol=1e-5)
+    dy = torch.randn(37, 512, generator=g)
+    yr.backward(dy)
+    dx = torch.empty(37, 512, dtype=torch.bfloat16, device="cuda")
+    ops.l2norm_bwd(dy.cuda(), y, inv, dx, 37, 512)
+    torch.testing.assert_close(dx.float().cpu(), fr.grad, atol=2e-3, rtol=2e-2)
+    w = torch.randn(70, 100, generator=g)
+    dst = torch.full((70, 128), 5.0, dtype=torch.bfloat16, device="cuda")
+    ops.cast_pad_bf16(w.cuda(), dst, 70, 100, 128)
+    assert torch.equal(dst[:, :100].cpu(), bf(w)) and float(dst[:, 100:].abs().max()) == 0.0
+    dt = torch.empty(100, 70, dtype=torch.bfloat16, device="cuda")
+    ops.cast_transpose_bf16(w.cuda(), dt, 70, 100)
+    assert torch.equal(dt.cpu(), bf(w).t())
+
+
+@pytest.mark.parametrize("P,S,d", [(8, 32, 64), (16, 224, 192), (14, 224, 64)])
+def test_im2col_embed(P, S, d):
+    ops = _ops()
+    B = 3
+    g = torch.Generator().manual_seed(P)
+    img = torch.randn(B, 3, S, S, generator=g)
+    G_ = S // P
+    L = G_ * G_ + 1
+    kp = 3 * P * P
+    kpad = (kp + 63) // 64 * 64
+    patches = torch.zeros(B * G_ * G_, kpad, dtype=torch.bfloat16, device="cuda")
+    ops.im2col(img.cuda(), patches, P)
+    assert torch.equal(patches[:, :kp].cpu(), bf(O.patchify(img, P).reshape(-1, kp)))
+    # embed + ln_pre fwd/bwd
+    patch_out = torch.randn(B * (L - 1), d, generator=g)
+    cls = torch.randn(d, generator=g); pos = torch.randn(L, d, generator=g)
+    gamma = torch.randn(d, generator=g); beta = torch.randn(d, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (patch_out, cls, pos, gamma, beta)]
+    po, c_, p_, g_, b_ = leaves
+    tok = torch.cat([c_.view(1, 1, d).expand(B, 1, d), po.view(B, L - 1, d)], 1) + p_
+    xref = O.layer_norm(tok, g_, b_)
+    dx = torch.randn(B * L, d, generator=g)
+    xref.backward(dx.view(B, L, d))
+    x = torch.empty(B * L, d, device="cuda"); mean = torch.empty(B * L, device="cuda"); rstd = torch.empty(B * L, device="cuda")
+    ops.embed_ln_fwd(patch_out.cuda(), cls.cuda(), pos.cuda(), gamma.cuda(), beta.cuda(), x, mean, rstd, B, L, d)
+    torch.testing.assert_close(x.cpu(), xref.detach().view(B * L, d), atol=1e-5, rtol=1e-5)
+    dres = dx.clone().cuda()
+    dpatch = torch.empty(B * (L - 1), d, dtype=torch.bfloat16, device="cuda")
+    dg = torch.empty(d, device="cuda"); db = torch.empty(d, device="cuda")
+    dpos = torch.empty(L, d, device="cuda"); dcls = torch.empty(d, device="cuda")
+    ops.embed_ln_bwd(dres, patch_out.cuda(), cls.cuda(), pos.cuda(), mean, rstd, gamma.cuda(), dpatch, dg, db, dpos, dcls, B, L, d)
+    torch.testing.assert_close(dpatch.float().cpu(), po.grad, atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(dg.cpu(), g_.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(db.cpu(), b_.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(dpos.cpu(), p_.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(dcls.cpu(), c_.grad, atol=1e-4, rtol=1e-4)
+
+
+def test_sgemm_all_layouts():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 70, 130, 45
+    a = torch.randn(M, K, generator=g); b = torch.randn(N, K, generator=g)
+    c = torch.zeros(M, N, device="cuda")
+    ops.sgemm(a.cuda(), K, 1, b.cuda(), K, 1, c, N, M, N, K)
+    torch.testing.assert_close(c.cpu(), a @ b.t(), atol=1e-4, rtol=1e-4)
+    at = a.t().contiguous(); btt = b.t().contiguous()
+    ops.sgemm(at.cuda(), 1, M, btt.cuda(), 1, N, c, N, M, N, K, accumulate=True)
+    torch.testing.assert_close(c.cpu(), 2 * (a @ b.t()), atol=2e-4, rtol=1e-4)
+
+
+def test_adamw_and_gradnorm():
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    n = 4 * 1000 + 4
+    p = torch.randn(n, generator=g); grads = [torch.randn(n, generator=g) * 3 for _ in range(3)]
+    pr = p.clone(); m = torch.zeros(n); v = torch.zeros(n)
+    pd, md, vd = p.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    nc = torch.empty(2, device="cuda")
+    W = 2
+    for step, gr in enumerate(grads, 1):
+        gavg = gr / W
+        norm = O.clip_grad_norm([gavg], 1.0)
+        O.adamw_step(pr, gavg, m, v, step, 1e-3)
+        ops.grad_norm(gr.cuda(), n, 1.0 / W, 1.0, nc)
+        assert abs(float(nc[0]) - float(norm)) < 1e-3 * float(norm)
+        ops.adamw_step(pd, gr.cuda(), md, vd, n, 1e-3, 0.9, 0.98, 1e-6, 0.1, step, 1.0 / W, nc)
+        torch.testing.assert_close(pd.cpu(), pr, atol=2e-6, rtol=1e-5)
