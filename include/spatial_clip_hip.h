@@ -26,7 +26,7 @@ int sc_abi_version(void);
 /* ------------------------------------------------------------------------------------------------ GEMM
  * bf16 MFMA GEMM, fp32 accumulate.  Replaces nn.Linear / nn.MultiheadAttention in_proj,out_proj / conv1
  * (patch embed as GEMM) forward, dgrad and wgrad:  src/open_clip/transformer.py:253,260-264,624-630.
- *   mode NT: C[M,N] = A[M,K] . B[N,K]^T   (K % 64 == 0)
+ *   mode NT: C[M,N] = A[M,K] . B[N,K]^T   (K % 8 == 0; K % 64 == 0 takes the fast path)
  *   mode TN: C[M,N] = At[K,M]^T . Bt[K,N] (weight gradients straight from row-major activations; any K)
  * epilogues:
  *   SC_EPI_BF16          C(bf16) = acc

@@ -40,9 +40,9 @@ struct GemmArgs {
     int ntm, ntn;
 };
 
-template <int MODE>
+template <int MODE, bool KTAIL>
 SC_DEVICE void stage_load(u32x4 (&ra)[4], u32x4 (&rb)[4], __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
-                          int lda, int ldb, int k0, int t) {
+                          int lda, int ldb, int k0, int t, int kend) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int c = p * 256 + t;
@@ -50,6 +50,10 @@ SC_DEVICE void stage_load(u32x4 (&ra)[4], u32x4 (&rb)[4], __amdgpu_buffer_rsrc_t
             const int row = c >> 3, kc = c & 7;
             ra[p] = sc_buf_load16(rsA, (uint32_t)(row * lda + k0 + kc * 8) * 2u);
             rb[p] = sc_buf_load16(rsB, (uint32_t)(row * ldb + k0 + kc * 8) * 2u);
+            if (KTAIL && k0 + kc * 8 >= kend) {   // K not a multiple of 64: zero the chunks past the row end
+                ra[p] = (u32x4){0u, 0u, 0u, 0u};
+                rb[p] = (u32x4){0u, 0u, 0u, 0u};
+            }
         } else {
             const int krow = c >> 4, mc = c & 15;
             ra[p] = sc_buf_load16(rsA, (uint32_t)((k0 + krow) * lda + mc * 8) * 2u);
@@ -77,7 +81,7 @@ SC_DEVICE void stage_store(const u32x4 (&ra)[4], const u32x4 (&rb)[4], char* sA,
     }
 }
 
-template <int MODE, int EPI>
+template <int MODE, int EPI, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
     u32x4 ra[4], rb[4];
     if (nt > 0) {
-        stage_load<MODE>(ra, rb, rsA, rsB, g.lda, g.ldb, kb, t);
+        stage_load<MODE, KTAIL>(ra, rb, rsA, rsB, g.lda, g.ldb, kb, t, kend);
         stage_store<MODE>(ra, rb, smem, smem + TILE_BYTES, t);
     }
     __syncthreads();
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         char* sA = smem + cur * 2 * TILE_BYTES;
         char* sB = sA + TILE_BYTES;
         const bool more = (it + 1 < nt);
-        if (more) stage_load<MODE>(ra, rb, rsA, rsB, g.lda, g.ldb, kb + (it + 1) * BK, t);
+        if (more) stage_load<MODE, KTAIL>(ra, rb, rsA, rsB, g.lda, g.ldb, kb + (it + 1) * BK, t, kend);
 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -251,17 +255,22 @@ __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __rest
     }
 }
 
-template <int MODE, int EPI>
-int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
+template <int MODE, int EPI, bool KTAIL>
+int launch1(const GemmArgs& g, int nblocks, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, EPI, KTAIL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
     }
-    gemm_kernel<MODE, EPI><<<nblocks, 256, LDS_BYTES, st>>>(g);
+    gemm_kernel<MODE, EPI, KTAIL><<<nblocks, 256, LDS_BYTES, st>>>(g);
     SC_LAUNCH_CHECK();
     return 0;
+}
+template <int MODE, int EPI>
+int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
+    if (MODE == SC_GEMM_NT && (g.K % BK) != 0) return launch1<MODE, EPI, true>(g, nblocks, st);
+    return launch1<MODE, EPI, false>(g, nblocks, st);
 }
 
 }  // namespace
@@ -272,11 +281,13 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     hipStream_t st = (hipStream_t)stream;
     SC_CHECK(mode == SC_GEMM_NT || mode == SC_GEMM_TN, "sc_gemm_bf16: bad mode %d", mode);
     SC_CHECK(M > 0 && N > 0 && K > 0, "sc_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
-    SC_CHECK((N % 8) == 0 && (ldc % 4) == 0, "sc_gemm_bf16: N (%d) must be a multiple of 8, ldc (%d) of 4", N, ldc);
+    const bool f32out = (epi == SC_EPI_F32 || epi == SC_EPI_F32_BIAS_RES);
+    SC_CHECK((N % (f32out ? 4 : 8)) == 0 && (ldc % 4) == 0,
+             "sc_gemm_bf16: N (%d) must be a multiple of %d, ldc (%d) of 4", N, f32out ? 4 : 8, ldc);
     SC_CHECK((lda % 8) == 0 && (ldb % 8) == 0, "sc_gemm_bf16: lda/ldb (%d,%d) must be multiples of 8", lda, ldb);
     SC_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
              "sc_gemm_bf16: operands must be 16-byte aligned");
-    if (mode == SC_GEMM_NT) SC_CHECK((K % BK) == 0, "sc_gemm_bf16: NT needs K %% 64 == 0 (K=%d)", K);
+    if (mode == SC_GEMM_NT) SC_CHECK((K % 8) == 0, "sc_gemm_bf16: NT needs K %% 8 == 0 (K=%d)", K);
     if (splitk < 1) splitk = 1;
     SC_CHECK(splitk == 1 || (epi == SC_EPI_F32 && slabs != nullptr), "sc_gemm_bf16: split-K needs EPI_F32 + slabs");
     GemmArgs g;

@@ -329,13 +329,10 @@ extern "C" int sc_cast_pad_bf16(const float* src, long long ld_src, void* dst, l
                                 int cols_pad, void* stream) {
     SC_CHECK(rows > 0 && cols > 0 && cols_pad >= cols && (cols_pad % 4) == 0 && (ld_dst % 4) == 0,
              "sc_cast_pad_bf16: bad shape rows=%d cols=%d pad=%d", rows, cols, cols_pad);
-    SC_CHECK((ld_src % 4) == 0 || cols_pad == cols || true, "unreachable");
     const long long nq = (long long)rows * (cols_pad / 4);
     int blocks = (int)((nq + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    // vector loads need 16-byte aligned rows; fall back to scalar gather inside the kernel otherwise
-    cast_pad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(src, ld_src, (bf16*)dst, ld_dst, rows,
-                                                             (ld_src % 4) == 0 ? cols : 0 * cols + cols, cols_pad);
+    cast_pad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(src, ld_src, (bf16*)dst, ld_dst, rows, cols, cols_pad);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,125 @@
+"""ClipLoss / SpatialLoss with the reference's constructor kwargs, forward kwargs and return contract
+(``{"contrastive_loss": 0-d tensor}``), computed by the fused device-side contrastive head.
+
+Mirrors ``src/models/components/losses.py:11-141`` (SpatialLoss; ClipLoss wrapper over open_clip's ClipLoss,
+``src/open_clip/loss.py:68-155``).  Distributed behaviour is the INTENDED one: rank / world size
+are read from the live process group at call time, the global batch is formed with one packed all-gather and the
+gradient of the gather (``gather_with_grad=True``) is one reduce-scatter."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import comm
+from .contrastive import contrastive_forward_backward
+
+
+class _ContrastiveFn(torch.autograd.Function):
+    """Forward computes the loss AND its feature / scale gradients (for an upstream gradient of 1); backward
+    scales them by the actual upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, image_features, text_features, logit_scale, owner, kw):
+        rank, W = comm.world()
+        if owner.world_size_override is not None:
+            rank, W = owner.rank_override, owner.world_size_override
+        ids_i, ids_t = kw.get("image_tile_ids"), kw.get("text_tile_ids")
+        img = image_features.detach().contiguous().float()
+        txt = text_features.detach().contiguous().float()
+        all_i, all_t, all_ids_i, all_ids_t = comm.gather_packed(img, txt, ids_i, ids_t)
+        res = contrastive_forward_backward(
+            img, txt, logit_scale.detach(), mode=owner.mode, all_image=all_i, all_text=all_t,
+            rank=rank if comm.is_dist() else 0,
+            image_tile_ids=ids_i, text_tile_ids=ids_t, all_image_tile_ids=all_ids_i, all_text_tile_ids=all_ids_t,
+            neighbor_tile_ids=kw.get("neighbor_tile_ids"), neighbor_alphas=kw.get("neighbor_alphas"),
+            cap_logit_scale=owner.cap_logit_scale, temp_reg_weight=owner.temp_reg_weight,
+            neighbor_alpha_scale=owner.neighbor_alpha_scale, logit_bias=kw.get("logit_bias"),
+            recall_hits=owner.recall_hits)
+        D = img.shape[1]
+        if owner.gather_with_grad or not comm.is_dist():
+            # autograd of torch.distributed.nn.all_gather (loss.py:50-52): SUM over ranks, keep own rows
+            both = comm.reduce_scatter_sum(torch.cat([res["d_all_image"], res["d_all_text"]], dim=1))
+            d_img = res["d_image"] + both[:, :D]
+            d_txt = res["d_text"] + both[:, D:]
+        else:
+            d_img, d_txt = res["d_image"], res["d_text"]       # loss.py:54-63 with local_loss: remote shards detached
+        ctx.save_for_backward(d_img, d_txt, res["d_scale"])
+        owner.last = res
+        return res["loss"].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        d_img, d_txt, d_s = ctx.saved_tensors
+        return d_img * g, d_txt * g, d_s * g, None, None
+
+
+class _LossBase(torch.nn.Module):
+    mode = "clip"
+    cap_logit_scale: Optional[float] = None
+    temp_reg_weight: float = 0.0
+    neighbor_alpha_scale: float = 1.0
+
+    def _init_common(self, local_loss, gather_with_grad, rank, world_size, use_horovod):
+        if use_horovod:
+            raise NotImplementedError("Horovod is out of scope (SURVEY.md 2.1); use torch.distributed / RCCL")
+        self.local_loss = local_loss
+        self.gather_with_grad = gather_with_grad
+        self.use_horovod = use_horovod
+        # explicit rank/world_size only matter for single-process emulation in tests; a live process group wins
+        self.rank_override, self.world_size_override = (rank, world_size) if world_size > 1 and not comm.is_dist() \
+            else (0, None)
+        self.recall_hits: Optional[torch.Tensor] = None
+        self.last: Dict[str, torch.Tensor] = {}
+
+    @property
+    def rank(self) -> int:
+        return comm.world()[0]
+
+    @property
+    def world_size(self) -> int:
+        return comm.world()[1]
+
+
+class ClipLoss(_LossBase):
+    """``ClipLoss(local_loss, gather_with_grad, cache_labels, rank, world_size, use_horovod)``; the global-batch
+    layout is always the memory-lean ``local_loss=True`` one ([B,G] per rank) -- for ``local_loss=False`` the
+    reference's full [G,G] loss equals the mean over ranks of these per-rank losses, which is what data-parallel
+    gradient averaging optimises anyway."""
+    mode = "clip"
+
+    def __init__(self, local_loss: bool = False, gather_with_grad: bool = False, cache_labels: bool = False,
+                 rank: int = 0, world_size: int = 1, use_horovod: bool = False):
+        super().__init__()
+        self._init_common(local_loss, gather_with_grad, rank, world_size, use_horovod)
+        self.cache_labels = cache_labels
+
+    def forward(self, image_features: torch.Tensor, text_features: torch.Tensor, logit_scale: torch.Tensor,
+                logit_bias: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        loss = _ContrastiveFn.apply(image_features, text_features, logit_scale, self, {"logit_bias": logit_bias})
+        return {"contrastive_loss": loss}
+
+
+class SpatialLoss(_LossBase):
+    """Multi-positive spatial-neighbour loss: soft labels from the tile-id join, STE-capped temperature,
+    temperature regulariser (losses.py:16-42 ctor, :44-124 forward)."""
+    mode = "spatial"
+
+    def __init__(self, local_loss: bool = False, gather_with_grad: bool = False, rank: int = 0, world_size: int = 1,
+                 use_horovod: bool = False, cap_logit_scale: Optional[float] = None, temp_reg_weight: float = 0.0,
+                 float32_logits: bool = False, neighbor_alpha_scale: float = 1.0):
+        super().__init__()
+        self._init_common(local_loss, gather_with_grad, rank, world_size, use_horovod)
+        self.cap_logit_scale = cap_logit_scale
+        self.temp_reg_weight = temp_reg_weight
+        self.float32_logits = float32_logits        # logits are always fp32 on this path
+        self.neighbor_alpha_scale = neighbor_alpha_scale
+
+    def forward(self, image_features: torch.Tensor, text_features: torch.Tensor, logit_scale: torch.Tensor,
+                image_tile_ids: torch.Tensor, text_tile_ids: torch.Tensor, neighbor_tile_ids: torch.Tensor,
+                neighbor_alphas: torch.Tensor, logit_bias: Optional[torch.Tensor] = None,
+                output_dict: bool = True) -> Dict[str, torch.Tensor]:
+        kw = {"image_tile_ids": image_tile_ids, "text_tile_ids": text_tile_ids,
+              "neighbor_tile_ids": neighbor_tile_ids, "neighbor_alphas": neighbor_alphas, "logit_bias": logit_bias}
+        loss = _ContrastiveFn.apply(image_features, text_features, logit_scale, self, kw)
+        return {"contrastive_loss": loss}

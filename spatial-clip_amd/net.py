@@ -1,0 +1,162 @@
+"""SpatialClipNet: the reference's two-tower wrapper, backed by the HIP towers.
+
+Mirror of ``src/models/components/spatial_clip_net.py:12-53`` (ctor kwargs ``model_name, pretrained, aug_cfg,
+cache_dir``; attributes ``model``, ``preprocess_train``, ``preprocess_val``, ``tokenizer``; ``forward(images,
+texts) -> {"image_features","text_features","logit_scale","logit_bias"}``).  The ``texts`` slot carries the float
+gene matrix [B, n_genes] for ``*-gene`` models.
+
+Autograd bridge: the whole net is ONE autograd node.  Its backward runs the hand-written backward kernel sequence
+and writes parameter gradients directly into the flat gradient buffer (``p.grad`` are views of it), so the usual
+``loss.backward(); optimizer.step()`` driver works unchanged.  Gradients are overwritten, not accumulated, by each
+backward (the reference path never uses gradient accumulation)."""
+from __future__ import annotations
+
+import os
+from dataclasses import is_dataclass
+from typing import Any, Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .model_configs import ModelCfg, get_model_config
+from .params import ParamStore
+from .towers import GeneTower, VisionTower
+
+OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)   # src/open_clip/constants.py:1-2
+OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class AugmentationCfg(dict):
+    """Stand-in for ``open_clip.AugmentationCfg`` (configs/model/spatial_clip.yaml:12-17): augmentation is CPU-side
+    data preparation outside the hot path; the values are kept for the data pipeline."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+
+
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, net, images, texts):
+        ctx.net = net
+        img = net.vision.forward(images)
+        txt = net.second.forward(texts)
+        s = torch.empty(1, dtype=torch.float32, device=img.device)
+        ops.exp_scalar(net.store.p("logit_scale").view(1), s)
+        net._scale = s
+        return img, txt, s.view(())
+
+    @staticmethod
+    def backward(ctx, d_img, d_txt, d_s):
+        ctx.net._backward(d_img, d_txt, d_s)
+        return None, None, None, None
+
+
+class _ClipFacade:
+    """What the reference reaches through ``net.model`` (encode_image / encode_text / logit_scale)."""
+
+    def __init__(self, net: "SpatialClipNet"):
+        self._net = net
+
+    @property
+    def logit_scale(self) -> torch.nn.Parameter:
+        return self._net.store.params["logit_scale"]
+
+    logit_bias = None
+
+    def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        if not normalize:
+            raise NotImplementedError("only normalize=True is on the hot path (spatial_clip_net.py:45)")
+        with torch.no_grad():
+            return self._net.vision.forward(image).clone()
+
+    def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        if not normalize:
+            raise NotImplementedError("only normalize=True is on the hot path (spatial_clip_net.py:46)")
+        with torch.no_grad():
+            return self._net.second.forward(text).clone()
+
+
+class SpatialClipNet(torch.nn.Module):
+    def __init__(self, model_name: str, pretrained: Optional[str] = None, aug_cfg: Optional[Any] = None,
+                 cache_dir: Optional[str] = None, n_genes: Optional[int] = None, gene_hidden: Optional[int] = None,
+                 device: Optional[str] = None, seed: int = 0, model_cfg: Optional[ModelCfg] = None):
+        super().__init__()
+        if aug_cfg is not None and not isinstance(aug_cfg, (dict, AugmentationCfg)) and not is_dataclass(aug_cfg) \
+                and not hasattr(aug_cfg, "items"):
+            raise TypeError(f"Unsupported type for aug_cfg: {type(aug_cfg)}")     # spatial_clip_net.py:33-34
+        self.aug_cfg = aug_cfg
+        if not torch.cuda.is_available():
+            raise RuntimeError("SpatialClipNet needs an MI355X (HIP device): this build has no CPU fallback")
+        self.device_ = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.cfg: ModelCfg = model_cfg if model_cfg is not None else get_model_config(model_name, n_genes, gene_hidden)
+        if self.cfg.gene is None:
+            raise NotImplementedError(
+                f"{model_name}: the reference CLIP text tower (SURVEY.md row T1) is not built yet in this round; "
+                f"use '{model_name}-gene' (gene-expression MLP tower)")
+        self.model_name = model_name
+        self.store = ParamStore(self.cfg, self.device_, seed=seed)
+        for name, p in self.store.params.items():
+            p._sc_store = self.store
+            self.register_parameter(name.replace(".", "__"), p)
+        self.vision = VisionTower(self.cfg, self.store)
+        self.second = GeneTower(self.cfg, self.store)
+        self.model = _ClipFacade(self)
+        self.preprocess_train = self.preprocess_val = self._preprocess
+        self.tokenizer = self._tokenizer
+        self.grad_bucket_hook: Optional[Callable[[int, int], None]] = None
+        if pretrained:
+            self._load_pretrained(pretrained)
+
+    # ------------------------------------------------------------------ reference-facing helpers
+    def _load_pretrained(self, pretrained: str) -> None:
+        if os.path.isfile(pretrained):        # local checkpoint path branch of factory.py:418-421
+            sd = torch.load(pretrained, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            self.store.load_state_dict({k: v for k, v in sd.items() if k in self.store.by_name}, strict=False)
+            return
+        # tags such as laion2b_s34b_b79k resolve to a hub download in the reference (pretrained.py:843,880-912)
+        raise RuntimeError(f"Pretrained weights ({pretrained}) for model {self.model_name} not found: "
+                           "no network access; pass a local state_dict path or pretrained=None")
+
+    @staticmethod
+    def _preprocess(img: torch.Tensor) -> torch.Tensor:
+        """Tensor-only stand-in for the torchvision pipeline: [3,H,W] float in [0,1] -> OPENAI mean/std normalised."""
+        mean = torch.tensor(OPENAI_DATASET_MEAN, dtype=img.dtype).view(3, 1, 1)
+        std = torch.tensor(OPENAI_DATASET_STD, dtype=img.dtype).view(3, 1, 1)
+        return (img - mean) / std
+
+    @staticmethod
+    def _tokenizer(x):
+        """Gene tower: the 'tokenizer' passes gene-expression vectors through as a float matrix."""
+        return torch.as_tensor(x, dtype=torch.float32)
+
+    def state_dict(self, *a, **k) -> Dict[str, torch.Tensor]:
+        return self.store.state_dict()
+
+    def load_state_dict(self, sd, strict: bool = True):
+        self.store.load_state_dict(sd, strict=strict)
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, images: torch.Tensor, texts: torch.Tensor) -> Dict[str, torch.Tensor]:
+        img, txt, s = _NetFn.apply(self.store.params["logit_scale"], self, images, texts)
+        return {"image_features": img, "text_features": txt, "logit_scale": s, "logit_bias": None}
+
+    def _bucket(self, names: List[str]) -> None:
+        if self.grad_bucket_hook is not None:
+            self.grad_bucket_hook(*self.store.grad_range(names))
+
+    def _backward(self, d_img, d_txt, d_s) -> None:
+        s = self.store
+        dev = self.device_
+        if d_s is None:
+            s.g("logit_scale").zero_()
+        else:
+            ops.exp_scalar_bwd(self._scale, d_s.reshape(1).float().contiguous(), s.g("logit_scale").view(1), 1.0)
+        self._bucket(["logit_scale"])
+        B, D = self.second.f.shape
+        if d_txt is None:
+            d_txt = torch.zeros((B, D), dtype=torch.float32, device=dev)
+        if d_img is None:
+            d_img = torch.zeros((B, D), dtype=torch.float32, device=dev)
+        self.second.backward(d_txt, on_bucket=self._bucket)
+        self.vision.backward(d_img, on_bucket=self._bucket)

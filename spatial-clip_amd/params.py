@@ -1,0 +1,235 @@
+"""Flat parameter store: every parameter of the model lives in ONE fp32 master buffer (plus one flat gradient
+buffer and two flat Adam moment buffers), laid out in forward order so that gradient buckets complete back to
+front during backward.  Named ``torch.nn.Parameter`` views (reference ``CLIP.state_dict()`` names:
+``visual.conv1.weight``, ``visual.transformer.resblocks.N.attn.in_proj_weight`` ...) keep checkpoint interop.
+
+bf16 compute copies of the GEMM weights (``wf`` = [N_out, K_in(pad)] for forward, ``wb`` = [K_in, N_out] for
+dgrad) are refreshed from the master buffer after each optimiser step."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .model_configs import ModelCfg
+
+ALIGN = 64  # floats
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class ParamSpec:
+    name: str
+    shape: Tuple[int, ...]
+    init: str                      # "uniform:<bound>", "normal:<std>", "ones", "zeros", "const:<v>"
+    offset: int = 0
+
+    @property
+    def numel(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+@dataclass
+class LinearCopy:
+    """bf16 copies of one GEMM weight.  ``stored_kn`` marks matrices the reference stores as [K_in, N_out]
+    (visual.proj, text_projection) instead of nn.Linear's [N_out, K_in]."""
+    name: str
+    n_out: int
+    k_in: int
+    stored_kn: bool = False
+    need_wb: bool = True
+    k_pad: int = 0
+    wf: Optional[torch.Tensor] = None
+    wb: Optional[torch.Tensor] = None
+
+
+def _block_specs(prefix: str, d: int, mlp: int) -> List[ParamSpec]:
+    """ResidualAttentionBlock parameters with torch's default initialisers
+    (src/open_clip/transformer.py:238-265; nn.MultiheadAttention._reset_parameters)."""
+    xav = math.sqrt(6.0 / (3 * d + d))
+    return [
+        ParamSpec(prefix + "ln_1.weight", (d,), "ones"),
+        ParamSpec(prefix + "ln_1.bias", (d,), "zeros"),
+        ParamSpec(prefix + "attn.in_proj_weight", (3 * d, d), f"uniform:{xav}"),
+        ParamSpec(prefix + "attn.in_proj_bias", (3 * d,), "zeros"),
+        ParamSpec(prefix + "attn.out_proj.weight", (d, d), f"uniform:{1.0 / math.sqrt(d)}"),
+        ParamSpec(prefix + "attn.out_proj.bias", (d,), "zeros"),
+        ParamSpec(prefix + "ln_2.weight", (d,), "ones"),
+        ParamSpec(prefix + "ln_2.bias", (d,), "zeros"),
+        ParamSpec(prefix + "mlp.c_fc.weight", (mlp, d), f"uniform:{1.0 / math.sqrt(d)}"),
+        ParamSpec(prefix + "mlp.c_fc.bias", (mlp,), f"uniform:{1.0 / math.sqrt(d)}"),
+        ParamSpec(prefix + "mlp.c_proj.weight", (d, mlp), f"uniform:{1.0 / math.sqrt(mlp)}"),
+        ParamSpec(prefix + "mlp.c_proj.bias", (d,), f"uniform:{1.0 / math.sqrt(mlp)}"),
+    ]
+
+
+def build_specs(cfg: ModelCfg) -> List[ParamSpec]:
+    """Parameter list in forward order.  Vision: src/open_clip/transformer.py:624-637,706 ; text:
+    TextTransformer.init_parameters ; logit_scale: src/open_clip/model.py:297-298 ; gene-MLP: nn.Linear defaults."""
+    v = cfg.vision
+    d = v.width
+    specs: List[ParamSpec] = []
+    fan_in = 3 * v.patch_size * v.patch_size
+    specs.append(ParamSpec("visual.conv1.weight", (d, 3, v.patch_size, v.patch_size), f"uniform:{1.0 / math.sqrt(fan_in)}"))
+    specs.append(ParamSpec("visual.class_embedding", (d,), f"normal:{d ** -0.5}"))
+    specs.append(ParamSpec("visual.positional_embedding", (v.tokens, d), f"normal:{d ** -0.5}"))
+    specs.append(ParamSpec("visual.ln_pre.weight", (d,), "ones"))
+    specs.append(ParamSpec("visual.ln_pre.bias", (d,), "zeros"))
+    for i in range(v.layers):
+        specs += _block_specs(f"visual.transformer.resblocks.{i}.", d, int(d * v.mlp_ratio))
+    specs.append(ParamSpec("visual.ln_post.weight", (d,), "ones"))
+    specs.append(ParamSpec("visual.ln_post.bias", (d,), "zeros"))
+    specs.append(ParamSpec("visual.proj", (d, cfg.embed_dim), f"normal:{d ** -0.5}"))
+    if cfg.text is not None:
+        t = cfg.text
+        specs.append(ParamSpec("token_embedding.weight", (t.vocab_size, t.width), "normal:0.02"))
+        specs.append(ParamSpec("positional_embedding", (t.context_length, t.width), "normal:0.01"))
+        for i in range(t.layers):
+            specs += _block_specs(f"transformer.resblocks.{i}.", t.width, int(t.width * t.mlp_ratio))
+        specs.append(ParamSpec("ln_final.weight", (t.width,), "ones"))
+        specs.append(ParamSpec("ln_final.bias", (t.width,), "zeros"))
+        specs.append(ParamSpec("text_projection", (t.width, cfg.embed_dim), f"normal:{t.width ** -0.5}"))
+    if cfg.gene is not None:
+        g = cfg.gene
+        specs.append(ParamSpec("gene.fc1.weight", (g.hidden, g.n_genes), f"uniform:{1.0 / math.sqrt(g.n_genes)}"))
+        specs.append(ParamSpec("gene.fc1.bias", (g.hidden,), f"uniform:{1.0 / math.sqrt(g.n_genes)}"))
+        specs.append(ParamSpec("gene.fc2.weight", (cfg.embed_dim, g.hidden), f"uniform:{1.0 / math.sqrt(g.hidden)}"))
+        specs.append(ParamSpec("gene.fc2.bias", (cfg.embed_dim,), f"uniform:{1.0 / math.sqrt(g.hidden)}"))
+    specs.append(ParamSpec("logit_scale", (), f"const:{cfg.init_logit_scale}"))
+    off = 0
+    for s in specs:
+        s.offset = off
+        off += _round_up(max(s.numel, 1), ALIGN)
+    return specs
+
+
+class ParamStore:
+    def __init__(self, cfg: ModelCfg, device: torch.device, seed: int = 0):
+        self.cfg = cfg
+        self.device = device
+        self.specs = build_specs(cfg)
+        self.by_name = {s.name: s for s in self.specs}
+        last = self.specs[-1]
+        self.total = last.offset + _round_up(max(last.numel, 1), ALIGN)
+        self.master = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.params: Dict[str, torch.nn.Parameter] = {}
+        for s in self.specs:
+            view = self.master[s.offset:s.offset + s.numel].view(s.shape)
+            p = torch.nn.Parameter(view, requires_grad=True)
+            p.grad = self.grad[s.offset:s.offset + s.numel].view(s.shape)
+            self.params[s.name] = p
+        self.copies: Dict[str, LinearCopy] = {}
+        self._build_copies()
+        self.init_parameters(seed)
+
+    # ------------------------------------------------------------------ views
+    def p(self, name: str) -> torch.Tensor:
+        s = self.by_name[name]
+        return self.master[s.offset:s.offset + s.numel].view(s.shape)
+
+    def g(self, name: str) -> torch.Tensor:
+        s = self.by_name[name]
+        return self.grad[s.offset:s.offset + s.numel].view(s.shape)
+
+    def grad_range(self, names: List[str]) -> Tuple[int, int]:
+        lo = min(self.by_name[n].offset for n in names)
+        hi = max(self.by_name[n].offset + _round_up(max(self.by_name[n].numel, 1), ALIGN) for n in names)
+        return lo, hi
+
+    def num_parameters(self) -> int:
+        return sum(s.numel for s in self.specs)
+
+    # ------------------------------------------------------------------ init / state dict
+    @torch.no_grad()
+    def init_parameters(self, seed: int = 0) -> None:
+        g = torch.Generator().manual_seed(seed)
+        for s in self.specs:
+            kind, _, arg = s.init.partition(":")
+            shape = s.shape if s.shape else (1,)
+            if kind == "uniform":
+                t = (torch.rand(shape, generator=g) * 2 - 1) * float(arg)
+            elif kind == "normal":
+                t = torch.randn(shape, generator=g) * float(arg)
+            elif kind == "ones":
+                t = torch.ones(shape)
+            elif kind == "zeros":
+                t = torch.zeros(shape)
+            else:
+                t = torch.full(shape, float(arg))
+            self.p(s.name).copy_(t.view(s.shape).to(self.device))
+        self.refresh_compute_copies()
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {s.name: self.p(s.name).detach().clone() for s in self.specs}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        missing = [s.name for s in self.specs if s.name not in sd]
+        unexpected = [k for k in sd if k not in self.by_name]
+        if strict and (missing or unexpected):
+            raise KeyError(f"state_dict mismatch: missing={missing[:5]} unexpected={unexpected[:5]}")
+        for s in self.specs:
+            if s.name in sd:
+                t = sd[s.name]
+                if tuple(t.shape) != tuple(s.shape):
+                    raise ValueError(f"{s.name}: shape {tuple(t.shape)} != {tuple(s.shape)}")
+                self.p(s.name).copy_(t.to(self.device, torch.float32))
+        self.refresh_compute_copies()
+
+    # ------------------------------------------------------------------ bf16 compute copies
+    def _add_copy(self, name: str, n_out: int, k_in: int, stored_kn: bool = False, need_wb: bool = True) -> None:
+        c = LinearCopy(name, n_out, k_in, stored_kn, need_wb, k_pad=_round_up(k_in, 64))
+        c.wf = torch.zeros((n_out, c.k_pad), dtype=torch.bfloat16, device=self.device)
+        if need_wb:
+            c.wb = torch.zeros((k_in, n_out), dtype=torch.bfloat16, device=self.device)
+        self.copies[name] = c
+
+    def _build_copies(self) -> None:
+        cfg = self.cfg
+        v = cfg.vision
+        d = v.width
+        self._add_copy("visual.conv1.weight", d, 3 * v.patch_size * v.patch_size, need_wb=False)
+
+        def block(prefix: str, dd: int, mlp: int) -> None:
+            self._add_copy(prefix + "attn.in_proj_weight", 3 * dd, dd)
+            self._add_copy(prefix + "attn.out_proj.weight", dd, dd)
+            self._add_copy(prefix + "mlp.c_fc.weight", mlp, dd)
+            self._add_copy(prefix + "mlp.c_proj.weight", dd, mlp)
+
+        for i in range(v.layers):
+            block(f"visual.transformer.resblocks.{i}.", d, int(d * v.mlp_ratio))
+        self._add_copy("visual.proj", cfg.embed_dim, d, stored_kn=True)
+        if cfg.text is not None:
+            t = cfg.text
+            for i in range(t.layers):
+                block(f"transformer.resblocks.{i}.", t.width, int(t.width * t.mlp_ratio))
+            self._add_copy("text_projection", cfg.embed_dim, t.width, stored_kn=True)
+        if cfg.gene is not None:
+            g = cfg.gene
+            self._add_copy("gene.fc1.weight", g.hidden, g.n_genes, need_wb=False)
+            self._add_copy("gene.fc2.weight", cfg.embed_dim, g.hidden)
+
+    def refresh_compute_copies(self) -> None:
+        """fp32 master -> bf16 GEMM operands (after init, load_state_dict and every optimiser step)."""
+        for c in self.copies.values():
+            src = self.p(c.name)
+            if c.stored_kn:
+                src2 = src.view(c.k_in, c.n_out)
+                ops.cast_transpose_bf16(src2, c.wf, c.k_in, c.n_out, ld_dst=c.k_pad)   # wf[n][k] = src[k][n]
+                if c.wb is not None:
+                    ops.cast_pad_bf16(src2, c.wb, c.k_in, c.n_out, c.n_out)
+            else:
+                src2 = src.view(c.n_out, c.k_in)
+                ops.cast_pad_bf16(src2, c.wf, c.n_out, c.k_in, c.k_pad, ld_src=c.k_in, ld_dst=c.k_pad)
+                if c.wb is not None:
+                    ops.cast_transpose_bf16(src2, c.wb, c.n_out, c.k_in, ld_dst=c.n_out)  # wb[k][n] = src[n][k]

@@ -1,0 +1,297 @@
+"""Encoder towers as explicit forward / backward kernel sequences over pre-allocated HBM buffers.
+
+No autograd graph, no tracing compiler: every step is a C-ABI kernel launch on the current HIP stream, the
+activations needed by backward live in buffers sized once per batch shape (288 GB of HBM3E make activation
+recomputation unnecessary at these sizes), parameter gradients are written straight into the flat fp32 gradient
+buffer of :class:`ParamStore`.
+
+Reference semantics: VisionTransformer.forward (src/open_clip/transformer.py:783-823,907-918),
+ResidualAttentionBlock.forward (:289-300), CLIP.encode_image (src/open_clip/model.py:326-328).
+Residual stream fp32, GEMM operands bf16 with fp32 accumulation, LayerNorm / softmax / normalisation in fp32 --
+the reference's ``precision: bf16-mixed`` autocast policy."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .model_configs import ModelCfg
+from .params import ParamStore
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _splitk_for(m_out: int, n_out: int, k: int) -> int:
+    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    ktiles = (k + 63) // 64
+    want = max(1, min(768 // max(tiles, 1), ktiles // 4))
+    return max(1, min(want, 32))
+
+
+class _Bufs:
+    """Named device buffers, (re)allocated when the requested shape changes."""
+
+    def __init__(self, device):
+        self.device = device
+        self._b: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype) -> torch.Tensor:
+        t = self._b.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._b[name] = t
+        return t
+
+    def bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._b.values())
+
+
+class TransformerStack:
+    """N pre-LN residual attention blocks (ResidualAttentionBlock, transformer.py:238-300)."""
+
+    def __init__(self, store: ParamStore, prefix: str, width: int, heads: int, layers: int, mlp: int, causal: bool):
+        self.s, self.prefix = store, prefix
+        self.d, self.H, self.layers, self.mlp, self.causal = width, heads, layers, mlp, causal
+        self.dh = width // heads
+        self.bufs = _Bufs(store.device)
+
+    def _n(self, i: int, leaf: str) -> str:
+        return f"{self.prefix}{i}.{leaf}"
+
+    def layer_param_names(self, i: int) -> List[str]:
+        leaves = ["ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                  "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                  "mlp.c_proj.weight", "mlp.c_proj.bias"]
+        return [self._n(i, l) for l in leaves]
+
+    # -------------------------------------------------------------------------------- forward
+    def forward(self, x0: torch.Tensor, B: int, L: int) -> torch.Tensor:
+        s, d, H, dh, mlp = self.s, self.d, self.H, self.dh, self.mlp
+        M = B * L
+        self.B, self.L, self.M = B, L, M
+        bf = self.bufs
+        x = x0
+        self.x_in = [None] * self.layers
+        for i in range(self.layers):
+            self.x_in[i] = x
+            a1 = bf.get(f"a1.{i}", (M, d), BF16)
+            m1 = bf.get(f"m1.{i}", (M,), F32)
+            r1 = bf.get(f"r1.{i}", (M,), F32)
+            ops.layernorm_fwd(x, s.p(self._n(i, "ln_1.weight")), s.p(self._n(i, "ln_1.bias")), a1, m1, r1, M, d)
+            qkv = bf.get(f"qkv.{i}", (M, 3 * d), BF16)
+            ops.gemm(ops.NT, ops.EPI_BF16_BIAS, a1, s.copies[self._n(i, "attn.in_proj_weight")].wf, qkv,
+                     M=M, N=3 * d, K=d, bias=s.p(self._n(i, "attn.in_proj_bias")))
+            o = bf.get(f"o.{i}", (M, d), BF16)
+            lse = bf.get(f"lse.{i}", (B, H, L), F32)
+            ops.attn_fwd(qkv, B, L, H, dh, self.causal, out=o, lse=lse)
+            xmid = bf.get(f"xmid.{i}", (M, d), F32)
+            ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, o, s.copies[self._n(i, "attn.out_proj.weight")].wf, xmid,
+                     M=M, N=d, K=d, bias=s.p(self._n(i, "attn.out_proj.bias")), res=x)
+            a2 = bf.get(f"a2.{i}", (M, d), BF16)
+            m2 = bf.get(f"m2.{i}", (M,), F32)
+            r2 = bf.get(f"r2.{i}", (M,), F32)
+            ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2, m2, r2, M, d)
+            u = bf.get(f"u.{i}", (M, mlp), BF16)
+            h = bf.get(f"h.{i}", (M, mlp), BF16)
+            ops.gemm(ops.NT, ops.EPI_GELU_PAIR, a2, s.copies[self._n(i, "mlp.c_fc.weight")].wf, u,
+                     M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)
+            xo = bf.get(f"xout.{i}", (M, d), F32)
+            ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, h, s.copies[self._n(i, "mlp.c_proj.weight")].wf, xo,
+                     M=M, N=d, K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
+            x = xo
+        return x
+
+    # -------------------------------------------------------------------------------- backward
+    def backward(self, dres: torch.Tensor, dres_bf: torch.Tensor, last_bias_colsum_done: bool,
+                 on_layer_done: Optional[Callable[[int], None]] = None) -> None:
+        """``dres`` (fp32) / ``dres_bf`` (bf16 copy) hold dL/d(output of the last block) on entry and
+        dL/d(input of block 0) on exit.  ``last_bias_colsum_done``: the caller already wrote the last block's
+        c_proj.bias gradient (column sum of dres)."""
+        s, d, H, dh, mlp = self.s, self.d, self.H, self.dh, self.mlp
+        B, L, M = self.B, self.L, self.M
+        bf = self.bufs
+        dU = bf.get("dU", (M, mlp), BF16)
+        dA = bf.get("dA", (M, d), BF16)
+        dO = bf.get("dO", (M, d), BF16)
+        dqkv = bf.get("dqkv", (M, 3 * d), BF16)
+        delta = bf.get("delta", (B, H, L), F32)
+        for i in reversed(range(self.layers)):
+            g = lambda leaf: s.g(self._n(i, leaf))
+            cp = lambda leaf: s.copies[self._n(i, leaf)]
+            a1, qkv, o = bf.get(f"a1.{i}", (M, d), BF16), bf.get(f"qkv.{i}", (M, 3 * d), BF16), bf.get(f"o.{i}", (M, d), BF16)
+            a2, u, h = bf.get(f"a2.{i}", (M, d), BF16), bf.get(f"u.{i}", (M, mlp), BF16), bf.get(f"h.{i}", (M, mlp), BF16)
+            xmid = bf.get(f"xmid.{i}", (M, d), F32)
+            lse = bf.get(f"lse.{i}", (B, H, L), F32)
+            if i == self.layers - 1 and not last_bias_colsum_done:
+                ops.colsum_bf16(dres_bf, M, d, g("mlp.c_proj.bias"))
+            # ---- MLP branch: x_out = xmid + c_proj(gelu(c_fc(ln_2(xmid))))
+            ops.gemm(ops.NT, ops.EPI_BF16_DGELU, dres_bf, cp("mlp.c_proj.weight").wb, dU, M=M, N=mlp, K=d, aux=u)
+            ops.gemm(ops.TN, ops.EPI_F32, dres_bf, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M,
+                     splitk=_splitk_for(d, mlp, M))
+            ops.gemm(ops.NT, ops.EPI_BF16, dU, cp("mlp.c_fc.weight").wb, dA, M=M, N=d, K=mlp)
+            ops.gemm(ops.TN, ops.EPI_F32, dU, a2, g("mlp.c_fc.weight"), M=mlp, N=d, K=M, splitk=_splitk_for(mlp, d, M))
+            ops.colsum_bf16(dU, M, mlp, g("mlp.c_fc.bias"))
+            # LN2 backward accumulates into the residual gradient; its column sum is out_proj.bias' gradient
+            ops.layernorm_bwd(dA, xmid, bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32),
+                              s.p(self._n(i, "ln_2.weight")), dres, dres_bf, g("ln_2.weight"), g("ln_2.bias"),
+                              g("attn.out_proj.bias"), M, d, accumulate=True)
+            # ---- attention branch: xmid = x_in + out_proj(attn(in_proj(ln_1(x_in))))
+            ops.gemm(ops.NT, ops.EPI_BF16, dres_bf, cp("attn.out_proj.weight").wb, dO, M=M, N=d, K=d)
+            ops.gemm(ops.TN, ops.EPI_F32, dres_bf, o, g("attn.out_proj.weight"), M=d, N=d, K=M,
+                     splitk=_splitk_for(d, d, M))
+            ops.attn_bwd(qkv, o, dO, lse, B, L, H, dh, self.causal, dqkv=dqkv, delta=delta)
+            ops.gemm(ops.NT, ops.EPI_BF16, dqkv, cp("attn.in_proj_weight").wb, dA, M=M, N=d, K=3 * d)
+            ops.gemm(ops.TN, ops.EPI_F32, dqkv, a1, g("attn.in_proj_weight"), M=3 * d, N=d, K=M,
+                     splitk=_splitk_for(3 * d, d, M))
+            ops.colsum_bf16(dqkv, M, 3 * d, g("attn.in_proj_bias"))
+            # LN1 backward; its column sum is the previous block's c_proj.bias gradient
+            prev_bias = s.g(self._n(i - 1, "mlp.c_proj.bias")) if i > 0 else None
+            ops.layernorm_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
+                              s.p(self._n(i, "ln_1.weight")), dres, dres_bf, g("ln_1.weight"), g("ln_1.bias"),
+                              prev_bias, M, d, accumulate=True)
+            if on_layer_done is not None:
+                on_layer_done(i)
+
+
+class VisionTower:
+    """VisionTransformer (pool 'tok', learnable pos-embed, ln_pre/ln_post, output projection) + L2 normalise."""
+
+    def __init__(self, cfg: ModelCfg, store: ParamStore):
+        v = cfg.vision
+        self.cfg, self.v, self.s = cfg, v, store
+        self.d, self.D, self.L = v.width, cfg.embed_dim, v.tokens
+        self.kp = 3 * v.patch_size * v.patch_size
+        self.kp_pad = store.copies["visual.conv1.weight"].k_pad
+        self.stack = TransformerStack(store, "visual.transformer.resblocks.", v.width, v.heads, v.layers,
+                                      int(v.width * v.mlp_ratio), causal=False)
+        self.bufs = _Bufs(store.device)
+
+    def param_names_head(self) -> List[str]:
+        return ["visual.ln_post.weight", "visual.ln_post.bias", "visual.proj"]
+
+    def param_names_stem(self) -> List[str]:
+        return ["visual.conv1.weight", "visual.class_embedding", "visual.positional_embedding",
+                "visual.ln_pre.weight", "visual.ln_pre.bias"]
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        s, v, d, D, L = self.s, self.v, self.d, self.D, self.L
+        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != v.image_size or images.shape[3] != v.image_size:
+            raise ValueError(f"images must be [B,3,{v.image_size},{v.image_size}], got {tuple(images.shape)}")
+        images = images.contiguous().float()
+        B = images.shape[0]
+        M, Mp = B * L, B * (L - 1)
+        self.B = B
+        bf = self.bufs
+        patches = bf.get("patches", (Mp, self.kp_pad), BF16)
+        if self.kp_pad != self.kp and getattr(self, "_pad_zeroed", None) is not patches:
+            patches.zero_()            # the K padding must be finite zeros; im2col only writes the real columns
+            self._pad_zeroed = patches
+        ops.im2col(images, patches, v.patch_size)
+        patch_out = bf.get("patch_out", (Mp, d), F32)
+        ops.gemm(ops.NT, ops.EPI_F32, patches, s.copies["visual.conv1.weight"].wf, patch_out, M=Mp, N=d, K=self.kp_pad)
+        x0 = bf.get("x0", (M, d), F32)
+        ops.embed_ln_fwd(patch_out, s.p("visual.class_embedding"), s.p("visual.positional_embedding"),
+                         s.p("visual.ln_pre.weight"), s.p("visual.ln_pre.bias"), x0,
+                         bf.get("m_pre", (M,), F32), bf.get("r_pre", (M,), F32), B, L, d)
+        xf = self.stack.forward(x0, B, L)
+        self.xf = xf
+        pooled = bf.get("pooled", (B, d), BF16)
+        ops.layernorm_fwd(xf, s.p("visual.ln_post.weight"), s.p("visual.ln_post.bias"), pooled,
+                          bf.get("m_post", (B,), F32), bf.get("r_post", (B,), F32), B, d, ldx=L * d)
+        f_raw = bf.get("f_raw", (B, D), F32)
+        ops.gemm(ops.NT, ops.EPI_F32, pooled, s.copies["visual.proj"].wf, f_raw, M=B, N=D, K=d)
+        f = torch.empty((B, D), dtype=F32, device=images.device)
+        ops.l2norm_fwd(f_raw, f, None, bf.get("inv", (B,), F32), B, D)
+        self.f = f
+        return f
+
+    def backward(self, d_f: torch.Tensor, on_bucket: Optional[Callable[[List[str]], None]] = None) -> None:
+        s, d, D, L, B = self.s, self.d, self.D, self.L, self.B
+        M, Mp = B * L, B * (L - 1)
+        bf = self.bufs
+        d_raw = bf.get("d_raw", (B, D), BF16)
+        ops.l2norm_bwd(d_f.contiguous().float(), self.f, bf.get("inv", (B,), F32), d_raw, B, D)
+        pooled = bf.get("pooled", (B, d), BF16)
+        d_pooled = bf.get("d_pooled", (B, d), BF16)
+        cp = s.copies["visual.proj"]
+        ops.gemm(ops.NT, ops.EPI_BF16, d_raw, cp.wb, d_pooled, M=B, N=d, K=D)
+        ops.gemm(ops.TN, ops.EPI_F32, pooled, d_raw, s.g("visual.proj"), M=d, N=D, K=B)
+        dres = bf.get("dres", (M, d), F32)
+        dres_bf = bf.get("dres_bf", (M, d), BF16)
+        dres.zero_()
+        dres_bf.zero_()
+        last = self.v.layers - 1
+        ops.layernorm_bwd(d_pooled, self.xf, bf.get("m_post", (B,), F32), bf.get("r_post", (B,), F32),
+                          s.p("visual.ln_post.weight"), dres, dres_bf, s.g("visual.ln_post.weight"),
+                          s.g("visual.ln_post.bias"), s.g(f"visual.transformer.resblocks.{last}.mlp.c_proj.bias"),
+                          B, d, accumulate=False, ldx=L * d, lddres=L * d, lddbf=L * d)
+        if on_bucket is not None:
+            on_bucket(self.param_names_head())
+        cb = (lambda i: on_bucket(self.stack.layer_param_names(i))) if on_bucket is not None else None
+        self.stack.backward(dres, dres_bf, last_bias_colsum_done=True, on_layer_done=cb)
+        # stem: ln_pre / positional / class embedding / conv1 (no gradient flows to the pixels)
+        dpatch = bf.get("dpatch", (Mp, d), BF16)
+        ops.embed_ln_bwd(dres, bf.get("patch_out", (Mp, d), F32), s.p("visual.class_embedding"),
+                         s.p("visual.positional_embedding"), bf.get("m_pre", (M,), F32), bf.get("r_pre", (M,), F32),
+                         s.p("visual.ln_pre.weight"), dpatch, s.g("visual.ln_pre.weight"), s.g("visual.ln_pre.bias"),
+                         s.g("visual.positional_embedding"), s.g("visual.class_embedding"), B, L, d)
+        gw = s.g("visual.conv1.weight").view(d, self.kp)
+        ops.gemm(ops.TN, ops.EPI_F32, dpatch, bf.get("patches", (Mp, self.kp_pad), BF16), gw, M=d, N=self.kp, K=Mp,
+                 splitk=_splitk_for(d, self.kp, Mp))
+        if on_bucket is not None:
+            on_bucket(self.param_names_stem())
+
+
+class GeneTower:
+    """Row G of SURVEY.md section 8a (no reference symbol): gene-expression MLP  n_genes -> hidden -(GELU)-> embed_dim,
+    L2-normalised; fills the ``texts`` slot of the batch with a float [B, n_genes] matrix."""
+
+    def __init__(self, cfg: ModelCfg, store: ParamStore):
+        g = cfg.gene
+        self.cfg, self.g, self.s = cfg, g, store
+        self.D = cfg.embed_dim
+        self.kpad = store.copies["gene.fc1.weight"].k_pad
+        self.bufs = _Bufs(store.device)
+
+    def param_names(self) -> List[str]:
+        return ["gene.fc1.weight", "gene.fc1.bias", "gene.fc2.weight", "gene.fc2.bias"]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        s, g, D = self.s, self.g, self.D
+        if x.dim() != 2 or x.shape[1] != g.n_genes:
+            raise ValueError(f"gene matrix must be [B,{g.n_genes}], got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        B = x.shape[0]
+        self.B = B
+        bf = self.bufs
+        xg = bf.get("xg", (B, self.kpad), BF16)
+        ops.cast_pad_bf16(x, xg, B, g.n_genes, self.kpad)
+        u1 = bf.get("u1", (B, g.hidden), BF16)
+        h1 = bf.get("h1", (B, g.hidden), BF16)
+        ops.gemm(ops.NT, ops.EPI_GELU_PAIR, xg, s.copies["gene.fc1.weight"].wf, u1, M=B, N=g.hidden, K=self.kpad,
+                 bias=s.p("gene.fc1.bias"), out2=h1)
+        f_raw = bf.get("f_raw", (B, D), F32)
+        ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, h1, s.copies["gene.fc2.weight"].wf, f_raw, M=B, N=D, K=g.hidden,
+                 bias=s.p("gene.fc2.bias"))
+        f = torch.empty((B, D), dtype=F32, device=x.device)
+        ops.l2norm_fwd(f_raw, f, None, bf.get("inv", (B,), F32), B, D)
+        self.f = f
+        return f
+
+    def backward(self, d_f: torch.Tensor, on_bucket: Optional[Callable[[List[str]], None]] = None) -> None:
+        s, g, D, B = self.s, self.g, self.D, self.B
+        bf = self.bufs
+        d_raw = bf.get("d_raw", (B, D), BF16)
+        ops.l2norm_bwd(d_f.contiguous().float(), self.f, bf.get("inv", (B,), F32), d_raw, B, D)
+        h1, u1 = bf.get("h1", (B, g.hidden), BF16), bf.get("u1", (B, g.hidden), BF16)
+        ops.gemm(ops.TN, ops.EPI_F32, d_raw, h1, s.g("gene.fc2.weight"), M=D, N=g.hidden, K=B)
+        ops.colsum_bf16(d_raw, B, D, s.g("gene.fc2.bias"))
+        dU = bf.get("dU", (B, g.hidden), BF16)
+        ops.gemm(ops.NT, ops.EPI_BF16_DGELU, d_raw, s.copies["gene.fc2.weight"].wb, dU, M=B, N=g.hidden, K=D, aux=u1)
+        ops.gemm(ops.TN, ops.EPI_F32, dU, bf.get("xg", (B, self.kpad), BF16), s.g("gene.fc1.weight"),
+                 M=g.hidden, N=g.n_genes, K=B)
+        ops.colsum_bf16(dU, B, g.hidden, s.g("gene.fc1.bias"))
+        if on_bucket is not None:
+            on_bucket(self.param_names())

@@ -1,0 +1,116 @@
+"""End-to-end GPU parity: HIP towers + fused contrastive head + fused AdamW against the fp32 CPU oracle on identical
+parameters and batches.  Tolerances: features <= 5e-3 abs (bf16 operands), loss <= 1e-3 (north-star), gradients
+<= 3 % of the tensor's max-abs (bf16 GEMM operands, fp32 accumulation)."""
+import pytest
+import torch
+
+from oracle import spatial_clip_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _pkg():
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data, losses, model_configs, module, net, optim
+    return data, losses, model_configs, module, net, optim
+
+
+def tiny_cfgs(width=64, head_width=32, layers=2, image=32, patch=8, embed=32, n_genes=100, hidden=64):
+    _, _, mc, _, _, _ = _pkg()
+    cfg = mc.ModelCfg(embed_dim=embed, vision=mc.VisionCfg(image, patch, width, layers, head_width),
+                      text=None, gene=mc.GeneCfg(n_genes, hidden))
+    ocfg = O.ModelCfg(embed_dim=embed, vision=O.VisionCfg(image, patch, width, layers, head_width), text=None,
+                      gene=O.GeneCfg(n_genes, hidden))
+    return cfg, ocfg
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def perturb(netobj, seed=11):
+    """Make biases / LN affine non-trivial so that their gradients are exercised."""
+    g = torch.Generator().manual_seed(seed)
+    sd = netobj.state_dict()
+    for k, v in sd.items():
+        if v.ndim == 1:
+            sd[k] = v.cpu() + 0.05 * torch.randn(v.shape, generator=g)
+    netobj.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("width,head_width,image,patch", [(64, 32, 32, 8), (128, 64, 48, 16)])
+@pytest.mark.parametrize("loss_kind", ["clip", "spatial"])
+def test_forward_backward_vs_oracle(width, head_width, image, patch, loss_kind):
+    data, losses, mc, module, net, optim = _pkg()
+    cfg, ocfg = tiny_cfgs(width, head_width, 2, image, patch)
+    B = 12
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=3)
+    perturb(n)
+    params = {k: v.cpu() for k, v in n.state_dict().items()}
+    batch = data.synthetic_batch(B, image, cfg.gene.n_genes, K=4, step=0)
+    # ---- oracle
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f = O.net_forward(batch["images"], batch["texts"], p, ocfg)
+    if loss_kind == "clip":
+        lo = O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"])
+        loss_fn = losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True)
+    else:
+        lo = O.spatial_loss(f["image_features"], f["text_features"], f["logit_scale"], batch["image_tile_ids"],
+                            batch["text_tile_ids"], batch["neighbor_tile_ids"], batch["neighbor_alphas"])
+        loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0,
+                                     temp_reg_weight=0.05, neighbor_alpha_scale=0.5, float32_logits=True)
+    lo.backward()
+    # ---- HIP
+    m = module.SpatialClipLitModule(n, loss_fn, None, None)
+    db = {k: v.cuda() for k, v in batch.items()}
+    out = m.model_step(db)
+    assert (out["image_features"].cpu() - f["image_features"].detach()).abs().max() < 5e-3
+    assert (out["text_features"].cpu() - f["text_features"].detach()).abs().max() < 5e-3
+    assert abs(float(out["loss"]) - float(lo.detach())) < 1e-3
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    bad = []
+    for k in params:
+        g_ref = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
+        g = n.store.g(k).cpu()
+        tol = 0.03 * float(g_ref.abs().max()) + 1e-6
+        if float((g - g_ref).abs().max()) > tol:
+            bad.append((k, float((g - g_ref).abs().max()), float(g_ref.abs().max())))
+    assert not bad, bad
+
+
+def test_three_training_steps_vs_oracle():
+    data, losses, mc, module, net, optim = _pkg()
+    import functools
+    cfg, ocfg = tiny_cfgs(64, 32, 2, 32, 8)
+    B = 16
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=5)
+    perturb(n)
+    params = {k: v.cpu() for k, v in n.state_dict().items()}
+    loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                 neighbor_alpha_scale=0.5, float32_logits=True)
+    m = module.SpatialClipLitModule(
+        n, loss_fn, functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=2))
+
+    class T:
+        max_steps, max_epochs, estimated_stepping_batches = 10, None, 10
+    m.trainer = T()
+    oc = m.configure_optimizers()
+    opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+    tr = O.OracleTrainer(ocfg, params, loss="spatial", lr=1e-3, warmup=2, total_steps=10)
+    for step in range(3):
+        batch = data.synthetic_batch(B, 32, cfg.gene.n_genes, K=4, step=step)
+        ref = tr.training_step(batch)
+        loss = m.training_step({k: v.cuda() for k, v in batch.items()}, step)
+        loss.backward()
+        nc = opt.step(grad_scale=1.0, max_norm=1.0)
+        sched.step()
+        assert abs(float(loss) - float(ref["loss"])) < 2e-3, (step, float(loss), float(ref["loss"]))
+        assert abs(float(nc[0]) - float(ref["grad_norm"])) < 0.03 * float(ref["grad_norm"]) + 1e-4
+    # after 3 AdamW steps the big weight matrices still track the oracle
+    for k in ("visual.proj", "gene.fc2.weight", "visual.transformer.resblocks.1.mlp.c_fc.weight"):
+        a, b = n.store.p(k).cpu(), tr.p[k].detach()
+        assert float((a - b).abs().max()) < 2.5e-3, k
+    r = m.train_metrics.compute()
+    assert 0.0 <= r["train/R@1"] <= r["train/R@5"] <= r["train/R@10"] <= 1.0
