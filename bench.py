@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tile-gene pairs/sec of the full Spatial-CLIP train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One "step" = forward (ViT image tower + gene tower) + global-batch contrastive loss + backward + gradient
+all-reduce (mean) + grad-norm clip 1.0 + AdamW + cosine-warmup scheduler step -- the reference's training_step
+plus what Lightning does after it.  Workload = BASELINE.json configs[1]/[2]: ViT-B/16 + gene-MLP
+(20000 -> 512 -> 512), local batch 256, ClipLoss over the RCCL-gathered global batch 256*N, synthetic 224x224
+tiles already resident in HBM.  Rank 0 prints ONE JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, Chip-level parameters)
+
+
+def flops_per_pair(cfg, G: int) -> float:
+    """Algorithmic train FLOPs per pair (2 FLOP/MAC, train = 3x forward, no padding/recompute)."""
+    v = cfg.vision
+    L, d, mlp, D = v.tokens, v.width, int(v.width * v.mlp_ratio), cfg.embed_dim
+    kp = 3 * v.patch_size ** 2
+    fwd = 2.0 * (L - 1) * kp * d
+    per_layer = 2.0 * L * d * 3 * d + 2 * (2.0 * L * L * d) + 2.0 * L * d * d + 2 * (2.0 * L * d * mlp)
+    fwd += v.layers * per_layer + 2.0 * d * D
+    if cfg.gene is not None:
+        fwd += 2.0 * cfg.gene.n_genes * cfg.gene.hidden + 2.0 * cfg.gene.hidden * D
+    fwd += 4.0 * G * D
+    return 3.0 * fwd
+
+
+def cpu_baseline(model_name: str, n_genes: int, B: int = 8, steps: int = 3):
+    """The oracle's fp32 train step timed on the host cores (reported baseline only)."""
+    import torch
+    from oracle import spatial_clip_oracle as O
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data, model_configs as mc
+    cfg = mc.get_model_config(model_name, n_genes)
+    v = cfg.vision
+    ocfg = O.ModelCfg(cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
+                      O.GeneCfg(cfg.gene.n_genes, cfg.gene.hidden))
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    tr = O.OracleTrainer(ocfg, O.init_params(ocfg, seed=0), loss="clip", lr=1e-3, warmup=2000)
+    rates = data.make_gene_rates(n_genes)
+    times = []
+    for s in range(steps + 1):
+        batch = data.synthetic_batch(B, v.image_size, n_genes, 8, s, gene_rates=rates)
+        t0 = time.time()
+        tr.training_step(batch)
+        times.append(time.time() - t0)
+    best = min(times[1:])
+    return {"value": B / best, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 train step ({model_name}, n_genes={n_genes}), B={B}, 1 warm-up + {steps} timed steps, best"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="local batch per GPU")
+    ap.add_argument("--model", default="ViT-B-16-gene")
+    ap.add_argument("--n-genes", type=int, default=20000)
+    ap.add_argument("--loss", default="clip", choices=["clip", "spatial"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    import functools
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import comm, data, losses, module, net, ops, optim
+
+    n = net.SpatialClipNet(args.model, None, n_genes=args.n_genes, seed=0)
+    cfg = n.cfg
+    if args.loss == "clip":
+        loss_fn = losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True)
+    else:
+        loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                     neighbor_alpha_scale=0.5, float32_logits=True)
+    m = module.SpatialClipLitModule(
+        n, loss_fn, functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=2000))
+
+    class _T:
+        max_steps, max_epochs, estimated_stepping_batches = 1_000_000, None, 1_000_000
+    m.trainer = _T()
+    oc = m.configure_optimizers()
+    opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+    reducer = comm.GradBucketReducer(n.store.grad)
+    n.grad_bucket_hook = reducer.bucket_ready if world > 1 else None
+
+    B = args.batch
+    rates = data.make_gene_rates(args.n_genes)
+    batches = []
+    for s in range(2):          # synthetic inputs resident in HBM before the timed region
+        b = data.synthetic_batch(B, cfg.vision.image_size, args.n_genes, 8, s, rank, world, rates)
+        batches.append({k: v.cuda() for k, v in b.items()})
+
+    def step(i):
+        loss = m.training_step(batches[i % 2], i)
+        loss.backward()
+        reducer.finish()
+        opt.step(grad_scale=1.0 / world, max_norm=1.0)
+        sched.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    if not args.no_kernel_events:
+        ops.KERNEL_EVENTS = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    pairs = B * world * args.steps
+    G = B * world
+    fpp = flops_per_pair(cfg, G)
+    value = pairs / dt
+
+    roofline = None
+    if events:
+        agg = {}
+        for name, fl, (e0, e1) in events:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        dom = "gemm_nt"
+        fl, sec, cnt = agg[dom]
+        ach = fl / sec / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel<NT> (forward + dgrad GEMMs)", "achieved": round(ach, 1),
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": cnt // args.steps,
+                    "avg_launch_us": round(sec / cnt * 1e6, 1), "flops_per_launch_avg": fl / cnt,
+                    "share_of_step_time": round(sec / dt, 3)}
+        if "gemm_tn" in agg:
+            fl2, sec2, cnt2 = agg["gemm_tn"]
+            roofline["wgrad_tn"] = {"achieved": round(fl2 / sec2 / 1e12, 1), "share_of_step_time": round(sec2 / dt, 3)}
+        step_tflops = value / world * fpp / 1e12
+        roofline["whole_step"] = {"achieved": round(step_tflops, 1), "frac": round(step_tflops / PEAK_BF16_TFLOPS, 4),
+                                  "flops_per_pair": fpp}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.model, args.n_genes)
+        out = {"metric": "tile-gene pairs/sec (train step)", "value": round(value, 2), "unit": "pairs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"{args.model} image tower + gene-MLP({args.n_genes}->{cfg.gene.hidden}->{cfg.embed_dim}), "
+                                      f"{cfg.vision.image_size}x{cfg.vision.image_size} tiles, local batch {B}, "
+                                      f"{'ClipLoss' if args.loss == 'clip' else 'SpatialLoss(k=8)'} over global batch {G}, "
+                                      "fwd+bwd+grad-allreduce+clip+AdamW", "global_batch": G,
+                          "parallelism": f"dp{world}", "loss": float(loss.detach())},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

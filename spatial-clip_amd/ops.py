@@ -60,12 +60,23 @@ def gemm(mode: int, epi: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tenso
         slabs = _slabs(n, out.device) if n else None
         if slabs is None:
             splitk = 1
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     rc = l.sc_gemm_bf16(mode, epi, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), M, N, K,
                         out.data_ptr(), out.stride(0), _ptr(out2), out2.stride(0) if out2 is not None else 0,
                         _ptr(bias), _ptr(res), res.stride(0) if res is not None else 0,
                         _ptr(aux), aux.stride(0) if aux is not None else 0, splitk, _ptr(slabs), _stream())
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append(("gemm_nt" if mode == NT else "gemm_tn", 2.0 * M * N * K, ev))
     check(rc, "sc_gemm_bf16")
     return out
+
+
+# bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream
+KERNEL_EVENTS = None
 
 
 # ------------------------------------------------------------------------------------------ workspace
