@@ -63,7 +63,17 @@ def cpu_baseline(model_name: str, n_genes: int, B: int = 8, steps: int = 3):
             "sample": f"oracle fp32 train step ({model_name}, n_genes={n_genes}), B={B}, 1 warm-up + {steps} timed steps, best"}
 
 
+def note(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.time() - T0:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T0 = time.time()
+
+
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(300, repeat=True, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -131,8 +141,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note(f"model + {len(batches)} batches resident; warm-up ({args.warmup} steps)")
     for i in range(args.warmup):
         step(i)
+        torch.cuda.synchronize()
+        note(f"warm-up step {i} done")
     fence()
     if not args.no_kernel_events:
         ops.KERNEL_EVENTS = []
@@ -141,6 +154,7 @@ def main():
         loss = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
+    note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -177,7 +191,9 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
+            note("timing the CPU oracle baseline (bounded sample)")
             cpu = cpu_baseline(args.model, args.n_genes)
+            note("cpu baseline done")
         out = {"metric": "tile-gene pairs/sec (train step)", "value": round(value, 2), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",

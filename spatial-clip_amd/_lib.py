@@ -50,6 +50,7 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  -- load torch's HIP runtime first so that the kernels share it (one libamdhip64)
         if not os.path.exists(LIB_PATH):
             raise SpatialClipHipError(
                 f"{LIB_PATH} is missing: build it with `python spatial-clip_amd/build.py` "
