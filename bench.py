@@ -34,6 +34,22 @@ def flops_per_pair(cfg, G: int) -> float:
     return 3.0 * fwd
 
 
+def host_cpu_share() -> int:
+    """Cores this process may really use: min(affinity, cgroup quota, SC_CPU_THREADS or 16 -- the GPU box's share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("SC_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(model_name: str, n_genes: int, B: int = 8, steps: int = 3):
     """The oracle's fp32 train step timed on the host cores (reported baseline only)."""
     import torch
@@ -44,11 +60,7 @@ def cpu_baseline(model_name: str, n_genes: int, B: int = 8, steps: int = 3):
     v = cfg.vision
     ocfg = O.ModelCfg(cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
                       O.GeneCfg(cfg.gene.n_genes, cfg.gene.hidden))
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cpu_share()
     torch.set_num_threads(cores)
     tr = O.OracleTrainer(ocfg, O.init_params(ocfg, seed=0), loss="clip", lr=1e-3, warmup=2000)
     rates = data.make_gene_rates(n_genes)

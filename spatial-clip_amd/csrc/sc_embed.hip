@@ -208,7 +208,7 @@ extern "C" int sc_embed_ln_fwd(const float* patch_out, const float* cls, const f
 
 extern "C" long long sc_embed_ln_bwd_ws_floats(int B, int L, int d) {
     int nblk = (B * L + 3) / 4;
-    if (nblk > 1024) nblk = 1024;
+    if (nblk > 256) nblk = 256;
     return (long long)nblk * 2 * d;
 }
 
@@ -219,7 +219,7 @@ extern "C" int sc_embed_ln_bwd(float* dres, const float* patch_out, const float*
     SC_CHECK(B > 0 && L > 1 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_embed_ln_bwd: bad shape B=%d L=%d d=%d", B, L, d);
     hipStream_t st = (hipStream_t)stream;
     int nblk = (B * L + 3) / 4;
-    if (nblk > 1024) nblk = 1024;
+    if (nblk > 256) nblk = 256;
     const size_t lds = (size_t)4 * 2 * d * sizeof(float);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel),

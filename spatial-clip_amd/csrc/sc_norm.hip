@@ -149,15 +149,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 }
 
 // out_k[c] = sum_b partial[b][k][c], k = 0..nvec-1 ; outputs may be null
-__global__ void colvec_finalize_kernel(const float* __restrict__ partial, int nblk, int nvec, int d,
-                                       float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nvec * d) return;
+// block = 64 columns x 4 partial groups (fixed summation order -> deterministic)
+__global__ __launch_bounds__(256) void colvec_finalize_kernel(const float* __restrict__ partial, int nblk, int nvec,
+                                                              int d, float* __restrict__ o0, float* __restrict__ o1,
+                                                              float* __restrict__ o2) {
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * nvec * d + e];
-    const int k = e / d, c = e - k * d;
-    float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
-    if (o) o[c] = s;
+    if (e < nvec * d)
+        for (int b = ty; b < nblk; b += 4) s += partial[(long long)b * nvec * d + e];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < nvec * d) {
+        s = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+        const int k = e / d, c = e - k * d;
+        float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
+        if (o) o[c] = s;
+    }
 }
 
 // ------------------------------------------------------------------ column sums of a bf16 matrix
@@ -264,7 +273,7 @@ extern "C" int sc_layernorm_fwd(const float* x, long long ldx, const float* gamm
 
 extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
     int nblk = (rows + 3) / 4;
-    if (nblk > 1024) nblk = 1024;
+    if (nblk > 256) nblk = 256;
     return (long long)nblk * 3 * d;
 }
 
@@ -275,7 +284,7 @@ extern "C" int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, 
     SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_bwd: bad shape rows=%d d=%d", rows, d);
     SC_CHECK(ws != nullptr, "sc_layernorm_bwd: workspace required");
     int nblk = (rows + 3) / 4;
-    if (nblk > 1024) nblk = 1024;
+    if (nblk > 256) nblk = 256;
     const size_t lds = (size_t)4 * 3 * d * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (lds > 48 * 1024) {
@@ -285,7 +294,7 @@ extern "C" int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, 
     ln_bwd_kernel<<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres,
                                           (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate);
     SC_LAUNCH_CHECK();
-    colvec_finalize_kernel<<<(3 * d + 255) / 256, 256, 0, st>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
+    colvec_finalize_kernel<<<(3 * d + 63) / 64, 256, 0, st>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -305,7 +314,7 @@ extern "C" int sc_colsum_bf16(const void* x, long long ld, int rows, int n, floa
     dim3 grid((n + 255) / 256, ny);
     colsum_kernel<<<grid, 256, 0, st>>>((const bf16*)x, ld, rows, n, ws);
     SC_LAUNCH_CHECK();
-    colvec_finalize_kernel<<<(n + 255) / 256, 256, 0, st>>>(ws, ny, 1, n, out, nullptr, nullptr);
+    colvec_finalize_kernel<<<(n + 63) / 64, 256, 0, st>>>(ws, ny, 1, n, out, nullptr, nullptr);
     SC_LAUNCH_CHECK();
     return 0;
 }
