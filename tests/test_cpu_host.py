@@ -1,0 +1,114 @@
+"""CPU-only checks (no GPU in the build container): the C-ABI library loads and exports every symbol the public
+header declares; host-side logic (model registry, parameter layout, schedule, synthetic data) behaves."""
+import ctypes
+import math
+import os
+
+import pytest
+import torch
+
+import spatial_clip_amd  # noqa: F401
+from spatial_clip_amd import _lib, data, model_configs as mc, optim, params
+from oracle import spatial_clip_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    decl = _lib.parse_header()
+    assert len(decl) >= 29 and "sc_gemm_bf16" in decl and "sc_attn_bwd" in decl
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    l = ctypes.CDLL(_lib.LIB_PATH)
+    for name in decl:
+        assert hasattr(l, name), name
+    assert _lib.lib().sc_abi_version() == 1
+
+
+def test_header_signatures_are_plain_c():
+    src = open(os.path.join(ROOT, "include", "spatial_clip_hip.h")).read()
+    assert "torch" not in src and "at::" not in src and "std::" not in src
+    for name, (_, args) in _lib.parse_header().items():
+        assert all(a in (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong) for a in args), name
+
+
+def test_argument_validation_without_gpu():
+    """Shape errors are rejected by the library before any launch (return < 0 + message)."""
+    l = _lib.lib()
+    rc = l.sc_gemm_bf16(0, 0, None, 8, None, 8, 0, 8, 64, None, 8, None, 0, None, None, 0, None, 0, 1, None, None)
+    assert rc < 0 and b"empty problem" in l.sc_last_error()
+    rc = l.sc_attn_fwd(None, None, None, 1, 1000, 1, 64, 0, None)
+    assert rc < 0 and b"L <=" in l.sc_last_error()
+    rc = l.sc_layernorm_fwd(None, 6, None, None, None, 6, None, None, 4, 6, 1e-5, None)
+    assert rc < 0
+
+
+def test_ops_refuse_cpu_tensors():
+    from spatial_clip_amd import ops
+    a = torch.zeros(64, 64, dtype=torch.bfloat16)
+    with pytest.raises(_lib.SpatialClipHipError):
+        ops.gemm(ops.NT, ops.EPI_BF16, a, a, a, M=64, N=64, K=64)
+
+
+def test_net_fails_loudly_without_gpu():
+    from spatial_clip_amd import net
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.SpatialClipNet("ViT-B-16-gene", None)
+
+
+def test_model_registry_matches_reference_manifest(golden_dir):
+    import json
+    man = json.load(open(os.path.join(golden_dir, "state_dict_manifest.json")))
+    for name in ("ViT-B-16", "ViT-L-14", "ViT-B-32"):
+        cfg = mc.get_model_config(name)
+        specs = {s.name: list(s.shape) for s in params.build_specs(cfg)}
+        ref = man[name]
+        assert set(specs) == set(ref), (set(specs) ^ set(ref))
+        for k, shp in ref.items():
+            assert specs[k] == shp, k
+    with pytest.raises(RuntimeError, match="not found"):
+        mc.get_model_config("ViT-nope")
+    g = mc.get_model_config("ViT-B-16-gene")
+    assert g.text is None and g.gene.n_genes == 20000 and g.vision.heads == 12 and g.vision.tokens == 197
+
+
+def test_param_layout_alignment_and_order():
+    cfg = mc.get_model_config("ViT-Ti-16-gene", n_genes=1000)
+    specs = params.build_specs(cfg)
+    offs = [s.offset for s in specs]
+    assert offs == sorted(offs) and all(o % params.ALIGN == 0 for o in offs)
+    for a, b in zip(specs, specs[1:]):
+        assert a.offset + a.numel <= b.offset
+    assert specs[-1].name == "logit_scale"
+
+
+def test_cosine_schedule_matches_oracle_and_lambdalr():
+    class Opt:
+        param_groups = [{"lr": 1e-3, "initial_lr": 1e-3}]
+    o = Opt()
+    s = optim.get_cosine_schedule_with_warmup(o, num_warmup_steps=5, num_training_steps=50)
+    lrs = []
+    for step in range(60):
+        lrs.append(o.param_groups[0]["lr"])
+        s.step()
+    assert lrs[0] == 0.0                                        # first optimiser step runs with lr = 0
+    for step, lr in enumerate(lrs):
+        assert abs(lr - 1e-3 * O.cosine_warmup_lambda(step, 5, 50)) < 1e-12
+    assert abs(lrs[5] - 1e-3) < 1e-12 and abs(lrs[50]) < 1e-12
+
+
+def test_synthetic_batch_contract():
+    b = data.synthetic_batch(16, 32, 50, K=8, step=3, rank=1, world_size=2)
+    assert b["images"].shape == (16, 3, 32, 32) and b["images"].dtype == torch.float32
+    assert b["texts"].shape == (16, 50) and b["texts"].dtype == torch.float32
+    assert b["image_tile_ids"].dtype == torch.int64 and torch.equal(b["image_tile_ids"], b["text_tile_ids"])
+    assert b["neighbor_tile_ids"].shape == (16, 8) and b["neighbor_alphas"].shape == (16, 8)
+    assert int(b["image_tile_ids"][0]) == 10_000 + 16              # rank 1 owns the second contiguous block
+    pad = b["neighbor_tile_ids"] < 0
+    assert float(b["neighbor_alphas"][pad].abs().sum()) == 0.0
+    rows = b["neighbor_alphas"].sum(1)
+    assert torch.allclose(rows[rows > 0], torch.ones_like(rows[rows > 0]), atol=1e-6)
+    dm = data.SyntheticSpatialDataModule(batch_size=4, image_size=32, n_genes=50)
+    with pytest.raises(ValueError):
+        dm.setup()
