@@ -10,35 +10,14 @@
 // The accumulators are produced "swapped" (D = B.A^T) so that every lane owns 4 consecutive columns
 // of C; they are then bounced through LDS once so that global stores / residual loads are full
 // 128..256-byte row segments.
-#include "sc_common.h"
-#include "sc_kernels.h"
+#include "sc_gemm_common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per operand tile
-constexpr int EPI_LD = 68;                         // floats per epilogue row (64 + 4 pad)
+constexpr int EPI_LD = SC_EPI_LD;
 constexpr int LDS_BYTES = 4 * 64 * EPI_LD * 4;     // 69632 >= 4 * TILE_BYTES
-
-struct GemmArgs {
-    const bf16* A;
-    const bf16* B;
-    int M, N, K;
-    int lda, ldb;
-    void* C;
-    int ldc;
-    void* C2;
-    int ldc2;
-    const float* bias;
-    const float* res;
-    int ldres;
-    const bf16* aux;
-    int ldaux;
-    int splitk;
-    int k_per_split;
-    long long slab_stride;
-    int ntm, ntn;
-};
 
 template <int MODE, bool KTAIL>
 SC_DEVICE void stage_load(u32x4 (&ra)[4], u32x4 (&rb)[4], __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB,
@@ -182,67 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): a wave only reads back its own region
     __builtin_amdgcn_wave_barrier();
 
-    const int gm0 = m0 + wm * 64, gn0 = n0 + wn * 64;
-    if (EPI == SC_EPI_F32 || EPI == SC_EPI_F32_BIAS_RES) {
-        float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.slab_stride;
-        const int col = (lane & 15) * 4;
-        const int gn = gn0 + col;
-        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (EPI == SC_EPI_F32_BIAS_RES && g.bias && gn < g.N) bv = *reinterpret_cast<const f32x4*>(g.bias + gn);
-#pragma unroll 4
-        for (int ps = 0; ps < 16; ++ps) {
-            const int row = ps * 4 + (lane >> 4);
-            const int gm = gm0 + row;
-            if (gm < g.M && gn < g.N) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EPI_LD + col);
-                if (EPI == SC_EPI_F32_BIAS_RES) {
-                    v += bv;
-                    if (g.res) v += *reinterpret_cast<const f32x4*>(g.res + (size_t)gm * g.ldres + gn);
-                }
-                *reinterpret_cast<f32x4*>(C + (size_t)gm * g.ldc + gn) = v;
-            }
-        }
-    } else {
-        bf16* C = reinterpret_cast<bf16*>(g.C);
-        const int col = (lane & 7) * 8;
-        const int gn = gn0 + col;
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-        if ((EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) && g.bias && gn < g.N) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + gn);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias + gn + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
-        }
-#pragma unroll 4
-        for (int ps = 0; ps < 8; ++ps) {
-            const int row = ps * 8 + (lane >> 3);
-            const int gm = gm0 + row;
-            if (gm < g.M && gn < g.N) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * EPI_LD + col);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + row * EPI_LD + col + 4);
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
-                if (EPI == SC_EPI_BF16_DGELU) {
-                    const bf16x8 u = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm * g.ldaux + gn);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= sc_gelu_grad((float)u[e]);
-                }
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *reinterpret_cast<bf16x8*>(C + (size_t)gm * g.ldc + gn) = o;
-                if (EPI == SC_EPI_GELU_PAIR) {
-                    bf16x8 h;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = (bf16)sc_gelu((float)o[e]);
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.C2) + (size_t)gm * g.ldc2 + gn) = h;
-                }
-            }
-        }
-    }
+    sc_epilogue_store<EPI>(ep, m0 + wm * 64, n0 + wn * 64, lane, g, z);
 }
 
 __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab,
@@ -294,6 +213,20 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
     g.aux = (const bf16*)aux; g.ldaux = ldaux;
+    const int took = sc_gemm256_try(mode, epi, g, splitk, slabs, (float*)C, st);
+    if (took < 0) return took;
+    if (took == 1) {
+        splitk = g.splitk;
+        if (splitk > 1) {
+            const long long n4 = (long long)M * N / 4;
+            int blocks = (int)((n4 + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            reduce_slabs_kernel<<<blocks, 256, 0, st>>>((float*)C, slabs, splitk, g.slab_stride, n4);
+            SC_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+    g.C = C;
     g.ntm = (M + BM - 1) / BM; g.ntn = (N + BN - 1) / BN;
     int ktiles = (K + BK - 1) / BK;
     if (splitk > ktiles) splitk = ktiles;

@@ -1,0 +1,194 @@
+// 256x256x64 bf16 MFMA GEMM for the big regular shapes of the ViT tower (M = B*197 tokens), gfx950.
+//   8 waves (2 x 4), each wave a 128x64 output tile = 8x4 MFMA 16x16x32 tiles (128 accumulator VGPRs),
+//   operands staged global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging
+//   VGPRs), double-buffered 2 x 64 KiB, one barrier per K tile; bank-conflict-free XOR swizzle applied on the
+//   per-lane SOURCE address (the DMA destination is lane-linear) and again on the fragment read;
+//   one workgroup per CU (139 KiB LDS), grid order XCD-aware so that the tiles sharing an A row-panel are
+//   neighbours in one L2.
+// Same operand layouts / epilogues as the 128x128 kernel (sc_gemm.hip), which remains the general fallback
+// (ragged K, tiny problems).  Edges in M/N are handled by clamping the source row/column (the duplicated
+// results are never stored); K (per split) must be a multiple of 64.
+#include "sc_gemm_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE = 256 * 64 * 2;                  // 32 KiB per operand tile
+constexpr int STAGE = 2 * TILE;                     // A + B
+constexpr int EPI_BYTES = 8 * 64 * SC_EPI_LD * 4;   // 139264
+constexpr int LDS_BYTES = EPI_BYTES > 2 * STAGE ? EPI_BYTES : 2 * STAGE;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// Issue the LDS-DMA of one K tile (A and B) : 8 wave-instructions per wave.
+template <int MODE>
+SC_DEVICE void stage_tile(const GemmArgs& g, char* sA, char* sB, int m0, int n0, int k0, int wave, int lane) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int grp = p * 8 + wave;                       // 32 groups of 1 KiB per operand tile
+        if (MODE == SC_GEMM_NT) {
+            const int r = grp * 8 + (lane >> 3);            // tile row, 128 B per row
+            const int lc = (lane & 7) ^ ((r >> 1) & 7);     // logical 16-byte chunk stored at physical lane&7
+            const int ra = min(m0 + r, g.M - 1), rb = min(n0 + r, g.N - 1);
+            dma16(g.A + (size_t)ra * g.lda + k0 + lc * 8, sA + grp * 1024);
+            dma16(g.B + (size_t)rb * g.ldb + k0 + lc * 8, sB + grp * 1024);
+        } else {
+            const int kr = grp * 2 + (lane >> 5);           // reduction row of the tile, 512 B per row
+            const int s = (kr & 3) | (((kr >> 3) & 1) << 2);
+            const int lc = (lane & 31) ^ (s << 1);
+            const int ca = min(m0 + lc * 8, g.M - 8), cb = min(n0 + lc * 8, g.N - 8);
+            dma16(g.A + (size_t)(k0 + kr) * g.lda + ca, sA + grp * 1024);
+            dma16(g.B + (size_t)(k0 + kr) * g.ldb + cb, sB + grp * 1024);
+        }
+    }
+}
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+
+    int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = idx % g.ntn;
+    idx /= g.ntn;
+    const int tm = idx % g.ntm;
+    const int z = idx / g.ntm;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nt = (kend - kbeg) / BK;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nt > 0) stage_tile<MODE>(g, smem, smem + TILE, m0, n0, kbeg, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int it = 0; it < nt; ++it) {
+        const int cur = it & 1;
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + TILE;
+        if (it + 1 < nt) {
+            char* nA = smem + (cur ^ 1) * STAGE;
+            stage_tile<MODE>(g, nA, nA + TILE, m0, n0, kbeg + (it + 1) * BK, wave, lane);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[8], bfr[4];
+            if (MODE == SC_GEMM_NT) {
+                const int coff = ((kk * 4 + lg) ^ ((li >> 1) & 7)) << 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + j * 16 + li) * 128 + coff);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(sA + (wm * 128 + i * 16 + li) * 128 + coff);
+            } else {
+                const int q = li >> 2, p = li & 3;
+                const int kr = kk * 32 + lg * 8 + q;
+                const int s = q | ((lg & 1) << 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const char* pb = sB + kr * 512 + (((wn * 4 + j) ^ s) << 5) + p * 8;
+                    bfr[j] = sc_cat(sc_lds_tr16(pb), sc_lds_tr16(pb + 4 * 512));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const char* pa = sA + kr * 512 + (((wm * 8 + i) ^ s) << 5) + p * 8;
+                    af[i] = sc_cat(sc_lds_tr16(pa), sc_lds_tr16(pa + 4 * 512));
+                }
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = sc_mfma16(bfr[j], af[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: two 64-row halves of the wave's 128x64 tile through a private LDS region ----------------
+    float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc_epi_put(ep, i, j, li, lg, acc[h * 4 + i][j]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        sc_epilogue_store<EPI>(ep, m0 + wm * 128 + h * 64, n0 + wn * 64, lane, g, z);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int MODE, int EPI>
+int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<MODE, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    gemm256_kernel<MODE, EPI><<<nblocks, 512, LDS_BYTES, st>>>(g);
+    SC_LAUNCH_CHECK();
+    return 1;
+}
+
+}  // namespace
+
+int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, float* c_final, hipStream_t st) {
+    // eligibility: enough work for 256-tiles, K a multiple of 64 per split, inner dims allow clamped 16-byte chunks
+    static const char* force = getenv("SC_GEMM_FORCE");      // "128": always the general kernel (A/B benchmarking)
+    if (force && force[0] == '1') return 0;
+    if (g.M < 256 || g.N < 192 || (g.K % BK) != 0) return 0;
+    if (mode == SC_GEMM_TN && ((g.M % 8) != 0 || (g.N % 8) != 0)) return 0;
+    const long long work = (long long)g.M * g.N;
+    if (work < 256LL * 256 * 8) return 0;
+    g.ntm = (g.M + BM - 1) / BM;
+    g.ntn = (g.N + BN - 1) / BN;
+    const int ktiles = g.K / BK;
+    int splitk = splitk_req < 1 ? 1 : splitk_req;
+    if (epi != SC_EPI_F32 || slabs == nullptr) splitk = 1;
+    if (splitk > ktiles) splitk = ktiles;
+    int tiles_per = (ktiles + splitk - 1) / splitk;
+    splitk = (ktiles + tiles_per - 1) / tiles_per;
+    g.splitk = splitk;
+    g.k_per_split = tiles_per * BK;
+    g.slab_stride = 0;
+    if (splitk > 1) {
+        if (g.ldc != g.N) return 0;
+        g.C = slabs;
+        g.slab_stride = (long long)g.M * g.N;
+    }
+    const int nblocks = g.ntm * g.ntn * splitk;
+    int rc = 0;
+#define SC_CASE(MODE, EPI) \
+    if (mode == MODE && epi == EPI) rc = launch<MODE, EPI>(g, nblocks, st);
+    SC_CASE(SC_GEMM_NT, SC_EPI_BF16)
+    SC_CASE(SC_GEMM_NT, SC_EPI_BF16_BIAS)
+    SC_CASE(SC_GEMM_NT, SC_EPI_F32_BIAS_RES)
+    SC_CASE(SC_GEMM_NT, SC_EPI_GELU_PAIR)
+    SC_CASE(SC_GEMM_NT, SC_EPI_BF16_DGELU)
+    SC_CASE(SC_GEMM_NT, SC_EPI_F32)
+    SC_CASE(SC_GEMM_TN, SC_EPI_F32)
+#undef SC_CASE
+    return rc;
+}

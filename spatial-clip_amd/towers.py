@@ -24,9 +24,10 @@ F32 = torch.float32
 
 
 def _splitk_for(m_out: int, n_out: int, k: int) -> int:
-    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    """Split-K factor for a weight-gradient GEMM: ~one 256x256 workgroup per CU (256 CUs)."""
+    tiles = ((m_out + 255) // 256) * ((n_out + 255) // 256)
     ktiles = (k + 63) // 64
-    want = max(1, min(768 // max(tiles, 1), ktiles // 4))
+    want = max(1, min((256 + tiles // 2) // max(tiles, 1), ktiles // 4))
     return max(1, min(want, 32))
 
 

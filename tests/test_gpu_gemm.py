@@ -20,7 +20,8 @@ def gelu(x):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 256, 128), (197 * 3, 192, 192), (1000, 576, 192),
-                                   (50, 64, 64), (394, 2304, 768), (300, 768, 3072)])
+                                   (50, 64, 64), (394, 2304, 768), (300, 768, 3072), (1024, 768, 768),
+                                   (197 * 8, 3072, 768), (513, 200, 128)])
 def test_nt_plain_and_bias(M, N, K):
     ops = _ops()
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -49,9 +50,9 @@ def test_nt_asymmetric_identity():
     assert torch.equal(o32.cpu(), a.float() @ b.float().t())
 
 
-def test_nt_residual_gelu_dgelu():
+@pytest.mark.parametrize("M,N,K", [(333, 192, 256), (197 * 4, 768, 192), (700, 264, 64)])
+def test_nt_residual_gelu_dgelu(M, N, K):
     ops = _ops()
-    M, N, K = 333, 192, 256
     g = torch.Generator().manual_seed(3)
     a, b = _rand((M, K), g), _rand((N, K), g, 0.1)
     bias = torch.randn(N, generator=g)
@@ -75,7 +76,9 @@ def test_nt_residual_gelu_dgelu():
 
 
 @pytest.mark.parametrize("M,N,K,splitk", [(128, 128, 64, 1), (192, 192, 197 * 2, 1), (768, 192, 1000, 4),
-                                          (576, 192, 37, 1), (2304, 768, 197 * 8, 8), (512, 20032, 8, 1)])
+                                          (576, 192, 37, 1), (2304, 768, 197 * 8, 8), (512, 20032, 8, 1),
+                                          (768, 768, 2048, 8), (2304, 768, 1024, 4), (768, 3072, 640, 1),
+                                          (512, 20000, 256, 1), (776, 200, 128, 2)])
 def test_tn_wgrad(M, N, K, splitk):
     ops = _ops()
     g = torch.Generator().manual_seed(K)
