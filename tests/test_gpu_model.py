@@ -114,3 +114,40 @@ def test_three_training_steps_vs_oracle():
         assert float((a - b).abs().max()) < 2.5e-3, k
     r = m.train_metrics.compute()
     assert 0.0 <= r["train/R@1"] <= r["train/R@5"] <= r["train/R@10"] <= 1.0
+
+
+def test_train_entry_smoke_shards(monkeypatch):
+    """BASELINE.json configs[0] through the Hydra surface: experiment=smoke_shards (ViT-Tiny + gene-MLP, batch 8)."""
+    monkeypatch.setenv("PROJECT_ROOT", "/tmp")
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import train
+    metrics = train.main(["experiment=smoke_shards"])
+    assert "train/loss" in metrics and metrics["train/loss"] == metrics["train/loss"]          # finite
+    assert "val/loss" in metrics and "test/loss" in metrics and 0.0 <= metrics["test/R@10"] <= 1.0
+
+
+def test_vit_tiny_224_loss_within_north_star_tolerance():
+    """ViT-Ti/16 at 224 px, 12 layers, batch 32: |loss - fp32 oracle| <= 1e-3 (the north-star bound)."""
+    data, losses, mc, module, net, optim = _pkg()
+    cfg = mc.get_model_config("ViT-Ti-16-gene", n_genes=2000)
+    v = cfg.vision
+    ocfg = O.ModelCfg(cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
+                      O.GeneCfg(2000, cfg.gene.hidden))
+    n = net.SpatialClipNet("ViT-Ti-16-gene", None, n_genes=2000, seed=2)
+    params = {k: v_.cpu() for k, v_ in n.state_dict().items()}
+    batch = data.synthetic_batch(32, 224, 2000, K=8)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        f = O.net_forward(batch["images"], batch["texts"], params, ocfg)
+        ref_c = O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"])
+        ref_s = O.spatial_loss(f["image_features"], f["text_features"], f["logit_scale"], batch["image_tile_ids"],
+                               batch["text_tile_ids"], batch["neighbor_tile_ids"], batch["neighbor_alphas"])
+    db = {k: v_.cuda() for k, v_ in batch.items()}
+    for ref, loss_fn in ((ref_c, losses.ClipLoss(local_loss=True, gather_with_grad=True)),
+                         (ref_s, losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0,
+                                                    temp_reg_weight=0.05, neighbor_alpha_scale=0.5))):
+        m = module.SpatialClipLitModule(n, loss_fn, None, None)
+        with torch.no_grad():
+            out = m.model_step(db)
+        assert (out["image_features"].cpu() - f["image_features"]).abs().max() < 5e-3
+        assert abs(float(out["loss"]) - float(ref)) < 1e-3, (float(out["loss"]), float(ref))
