@@ -96,6 +96,20 @@ int sc_embed_ln_bwd(float* dres, const float* patch_out, const float* cls, const
                     const float* rstd, const float* gamma, void* dpatch_bf16, float* dgamma, float* dbeta,
                     float* dpos, float* dcls, float* ws, int B, int L, int d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ text tower glue
+ * CLIP.encode_text (src/open_clip/model.py:330-345): x = token_embedding[text] + positional_embedding (fp32 residual
+ * stream [B*L, d]); pooling = row at text.argmax(-1) (EOT has the largest id; src/open_clip/transformer.py:931-934).
+ * Backward: dtable is zeroed then scatter-added with float atomics (duplicate tokens), dpos[t] = sum_b dres[b,t].
+ * gather/scatter move the pooled rows between the [B*L, d] stream and a compact [B, d] buffer. */
+int sc_token_embed_fwd(const long long* tokens, const float* table, const float* pos, float* x, int B, int L, int d,
+                       int V, void* stream);
+int sc_token_embed_bwd(const long long* tokens, const float* dres, float* dtable, float* dpos, int B, int L, int d,
+                       int V, void* stream);
+int sc_argmax_rows_i64(const long long* tokens, int* out_idx, int B, int L, void* stream);
+int sc_gather_rows_f32(const float* src, const int* idx, int L, float* dst, int B, int d, void* stream);
+int sc_scatter_rows_f32(const float* src, const int* idx, int L, float* dst, void* dst_bf16, int B, int d,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------------ contrastive head
  * ClipLoss (src/open_clip/loss.py:91-155, local_loss layout) and SpatialLoss
  * (src/models/components/losses.py:44-124) on the device.  z[2][B][G] holds the cosine similarities

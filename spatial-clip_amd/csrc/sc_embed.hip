@@ -236,3 +236,126 @@ extern "C" int sc_embed_ln_bwd(float* dres, const float* patch_out, const float*
     (void)hipMemcpyAsync(dcls, dpos, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, st);
     return 0;
 }
+
+// ============================================================================================ text tower glue
+// CLIP.encode_text (src/open_clip/model.py:330-345): token_embedding gather + positional embedding; EOT pooling
+// = row at text.argmax(-1) (src/open_clip/transformer.py:931-934).
+namespace {
+
+__global__ void token_embed_fwd_kernel(const long long* __restrict__ tokens, const float* __restrict__ table,
+                                       const float* __restrict__ pos, float* __restrict__ x, int rows, int L, int d,
+                                       int V) {
+    const int nv = d >> 2;
+    const long long total = (long long)rows * nv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / nv), e = (int)(i - (long long)r * nv) * 4;
+        long long tk = tokens[r];
+        tk = tk < 0 ? 0 : (tk >= V ? V - 1 : tk);
+        const f32x4 v = ld4(table + tk * d + e) + ld4(pos + (long long)(r % L) * d + e);
+        st4(x + (long long)r * d + e, v);
+    }
+}
+
+__global__ void token_embed_bwd_kernel(const long long* __restrict__ tokens, const float* __restrict__ dres,
+                                       float* __restrict__ dtable, int rows, int d, int V) {
+    const long long total = (long long)rows * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / d), e = (int)(i - (long long)r * d);
+        const float g = dres[i];
+        if (g != 0.f) {
+            long long tk = tokens[r];
+            tk = tk < 0 ? 0 : (tk >= V ? V - 1 : tk);
+            atomicAdd(dtable + tk * d + e, g);
+        }
+    }
+}
+
+__global__ void argmax_rows_kernel(const long long* __restrict__ tokens, int* __restrict__ out, int B, int L) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    long long best = tokens[(long long)b * L];
+    int bi = 0;
+    for (int t = 1; t < L; ++t) {
+        const long long v = tokens[(long long)b * L + t];
+        if (v > best) { best = v; bi = t; }      // first maximum, like torch.argmax
+    }
+    out[b] = bi;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int L,
+                                   float* __restrict__ dst, int B, int d) {
+    const int nv = d >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nv) return;
+    const int b = i / nv, e = (i - b * nv) * 4;
+    st4(dst + (long long)b * d + e, ld4(src + ((long long)b * L + idx[b]) * d + e));
+}
+
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int L,
+                                    float* __restrict__ dst, bf16* __restrict__ dst_bf, int B, int d) {
+    const int nv = d >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nv) return;
+    const int b = i / nv, e = (i - b * nv) * 4;
+    const f32x4 v = ld4(src + (long long)b * d + e);
+    const long long row = (long long)b * L + idx[b];
+    st4(dst + row * d + e, v);
+    if (dst_bf) {
+        bf16x4 o;
+        o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+        *reinterpret_cast<bf16x4*>(dst_bf + row * d + e) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_token_embed_fwd(const long long* tokens, const float* table, const float* pos, float* x, int B, int L,
+                                  int d, int V, void* stream) {
+    SC_CHECK(B > 0 && L > 0 && d > 0 && (d % 4) == 0 && V > 0, "sc_token_embed_fwd: bad shape");
+    const long long total = (long long)B * L * (d / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    token_embed_fwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(tokens, table, pos, x, B * L, L, d, V);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_token_embed_bwd(const long long* tokens, const float* dres, float* dtable, float* dpos, int B, int L,
+                                  int d, int V, void* stream) {
+    SC_CHECK(B > 0 && L > 0 && d > 0 && (d % 4) == 0 && V > 0, "sc_token_embed_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(dtable, 0, (size_t)V * d * sizeof(float), st);
+    const long long total = (long long)B * L * d;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    token_embed_bwd_kernel<<<blocks, 256, 0, st>>>(tokens, dres, dtable, B * L, d, V);
+    SC_LAUNCH_CHECK();
+    const long long n4 = (long long)L * d / 4;
+    batch_sum_kernel<<<(int)((n4 + 255) / 256), 256, 0, st>>>(dres, dpos, B, n4);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_argmax_rows_i64(const long long* tokens, int* out_idx, int B, int L, void* stream) {
+    SC_CHECK(B > 0 && L > 0, "sc_argmax_rows_i64: bad shape");
+    argmax_rows_kernel<<<(B + 255) / 256, 256, 0, (hipStream_t)stream>>>(tokens, out_idx, B, L);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_gather_rows_f32(const float* src, const int* idx, int L, float* dst, int B, int d, void* stream) {
+    SC_CHECK(B > 0 && d > 0 && (d % 4) == 0, "sc_gather_rows_f32: bad shape");
+    gather_rows_kernel<<<(B * (d / 4) + 255) / 256, 256, 0, (hipStream_t)stream>>>(src, idx, L, dst, B, d);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_scatter_rows_f32(const float* src, const int* idx, int L, float* dst, void* dst_bf16, int B, int d,
+                                   void* stream) {
+    SC_CHECK(B > 0 && d > 0 && (d % 4) == 0, "sc_scatter_rows_f32: bad shape");
+    scatter_rows_kernel<<<(B * (d / 4) + 255) / 256, 256, 0, (hipStream_t)stream>>>(src, idx, L, dst, (bf16*)dst_bf16, B, d);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

@@ -20,7 +20,7 @@ import torch
 from . import ops
 from .model_configs import ModelCfg, get_model_config
 from .params import ParamStore
-from .towers import GeneTower, VisionTower
+from .towers import GeneTower, TextTower, VisionTower
 
 OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)   # src/open_clip/constants.py:1-2
 OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -89,17 +89,15 @@ class SpatialClipNet(torch.nn.Module):
             raise RuntimeError("SpatialClipNet needs an MI355X (HIP device): this build has no CPU fallback")
         self.device_ = torch.device(device or f"cuda:{torch.cuda.current_device()}")
         self.cfg: ModelCfg = model_cfg if model_cfg is not None else get_model_config(model_name, n_genes, gene_hidden)
-        if self.cfg.gene is None:
-            raise NotImplementedError(
-                f"{model_name}: the reference CLIP text tower (SURVEY.md row T1) is not built yet in this round; "
-                f"use '{model_name}-gene' (gene-expression MLP tower)")
+        if self.cfg.gene is None and self.cfg.text is None:
+            raise ValueError(f"{model_name}: the model config has neither a text tower nor a gene tower")
         self.model_name = model_name
         self.store = ParamStore(self.cfg, self.device_, seed=seed)
         for name, p in self.store.params.items():
             p._sc_store = self.store
             self.register_parameter(name.replace(".", "__"), p)
         self.vision = VisionTower(self.cfg, self.store)
-        self.second = GeneTower(self.cfg, self.store)
+        self.second = GeneTower(self.cfg, self.store) if self.cfg.gene is not None else TextTower(self.cfg, self.store)
         self.model = _ClipFacade(self)
         self.preprocess_train = self.preprocess_val = self._preprocess
         self.tokenizer = self._tokenizer
@@ -125,10 +123,15 @@ class SpatialClipNet(torch.nn.Module):
         std = torch.tensor(OPENAI_DATASET_STD, dtype=img.dtype).view(3, 1, 1)
         return (img - mean) / std
 
-    @staticmethod
-    def _tokenizer(x):
-        """Gene tower: the 'tokenizer' passes gene-expression vectors through as a float matrix."""
-        return torch.as_tensor(x, dtype=torch.float32)
+    def _tokenizer(self, x):
+        """Gene tower: the 'tokenizer' passes gene-expression vectors through as a float matrix.  Text tower: token
+        ids pass through; BPE tokenisation of strings is CPU-side data preparation outside the hot path."""
+        if self.cfg.gene is not None:
+            return torch.as_tensor(x, dtype=torch.float32)
+        if isinstance(x, (str, list)) and (isinstance(x, str) or (x and isinstance(x[0], str))):
+            raise NotImplementedError("BPE tokenisation (src/open_clip/tokenizer.py) is out of scope: pass int64 "
+                                      "[B, context_length] token ids")
+        return torch.as_tensor(x, dtype=torch.int64)
 
     def state_dict(self, *a, **k) -> Dict[str, torch.Tensor]:
         return self.store.state_dict()

@@ -263,3 +263,33 @@ def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_scale, norm_
     check(_lib.lib().sc_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(lr), float(beta1),
                                    float(beta2), float(eps), float(wd), int(step), float(grad_scale), _ptr(norm_clip),
                                    _stream()), "sc_adamw_step")
+
+
+# ------------------------------------------------------------------------------------------ text tower glue
+def token_embed_fwd(tokens, table, pos, x, B, L, d, V):
+    _req(tokens, torch.int64, "tokens")
+    check(_lib.lib().sc_token_embed_fwd(tokens.data_ptr(), table.data_ptr(), pos.data_ptr(), x.data_ptr(), B, L, d, V,
+                                        _stream()), "sc_token_embed_fwd")
+    return x
+
+
+def token_embed_bwd(tokens, dres, dtable, dpos, B, L, d, V):
+    check(_lib.lib().sc_token_embed_bwd(tokens.data_ptr(), dres.data_ptr(), dtable.data_ptr(), dpos.data_ptr(), B, L, d,
+                                        V, _stream()), "sc_token_embed_bwd")
+
+
+def argmax_rows(tokens, out_idx, B, L):
+    _req(tokens, torch.int64, "tokens")
+    check(_lib.lib().sc_argmax_rows_i64(tokens.data_ptr(), out_idx.data_ptr(), B, L, _stream()), "sc_argmax_rows_i64")
+    return out_idx
+
+
+def gather_rows(src, idx, L, dst, B, d):
+    check(_lib.lib().sc_gather_rows_f32(src.data_ptr(), idx.data_ptr(), L, dst.data_ptr(), B, d, _stream()),
+          "sc_gather_rows_f32")
+    return dst
+
+
+def scatter_rows(src, idx, L, dst, dst_bf16, B, d):
+    check(_lib.lib().sc_scatter_rows_f32(src.data_ptr(), idx.data_ptr(), L, dst.data_ptr(), _ptr(dst_bf16), B, d,
+                                         _stream()), "sc_scatter_rows_f32")

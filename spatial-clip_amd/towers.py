@@ -296,3 +296,79 @@ class GeneTower:
         ops.colsum_bf16(dU, B, g.hidden, s.g("gene.fc1.bias"))
         if on_bucket is not None:
             on_bucket(self.param_names())
+
+
+class TextTower:
+    """The reference's second tower: CLIP text transformer on BPE token ids (CLIP.encode_text,
+    src/open_clip/model.py:330-345): embedding gather + positional embedding, causal pre-LN blocks, ln_final, EOT
+    (argmax id) pooling, text_projection, L2 normalise.  ln_final is per token, so only the pooled rows are
+    normalised (the reference normalises all 77 and then picks one)."""
+
+    def __init__(self, cfg: ModelCfg, store: ParamStore):
+        t = cfg.text
+        self.cfg, self.t, self.s = cfg, t, store
+        self.d, self.D, self.L, self.V = t.width, cfg.embed_dim, t.context_length, t.vocab_size
+        self.stack = TransformerStack(store, "transformer.resblocks.", t.width, t.heads, t.layers,
+                                      int(t.width * t.mlp_ratio), causal=True)
+        self.bufs = _Bufs(store.device)
+
+    def param_names_head(self) -> List[str]:
+        return ["ln_final.weight", "ln_final.bias", "text_projection"]
+
+    def param_names_stem(self) -> List[str]:
+        return ["token_embedding.weight", "positional_embedding"]
+
+    def forward(self, text: torch.Tensor) -> torch.Tensor:
+        s, d, D, L = self.s, self.d, self.D, self.L
+        if text.dim() != 2 or text.shape[1] != L or text.dtype != torch.int64:
+            raise ValueError(f"texts must be int64 [B,{L}] token ids, got {tuple(text.shape)} {text.dtype}")
+        text = text.contiguous()
+        B = text.shape[0]
+        M = B * L
+        self.B, self.text = B, text
+        bf = self.bufs
+        x0 = bf.get("x0", (M, d), F32)
+        ops.token_embed_fwd(text, s.p("token_embedding.weight"), s.p("positional_embedding"), x0, B, L, d, self.V)
+        xf = self.stack.forward(x0, B, L)
+        eot = bf.get("eot", (B,), torch.int32)
+        ops.argmax_rows(text, eot, B, L)
+        xe = bf.get("x_eot", (B, d), F32)
+        ops.gather_rows(xf, eot, L, xe, B, d)
+        pooled = bf.get("pooled", (B, d), BF16)
+        ops.layernorm_fwd(xe, s.p("ln_final.weight"), s.p("ln_final.bias"), pooled, bf.get("m_post", (B,), F32),
+                          bf.get("r_post", (B,), F32), B, d)
+        f_raw = bf.get("f_raw", (B, D), F32)
+        ops.gemm(ops.NT, ops.EPI_F32, pooled, s.copies["text_projection"].wf, f_raw, M=B, N=D, K=d)
+        f = torch.empty((B, D), dtype=F32, device=text.device)
+        ops.l2norm_fwd(f_raw, f, None, bf.get("inv", (B,), F32), B, D)
+        self.f = f
+        return f
+
+    def backward(self, d_f: torch.Tensor, on_bucket: Optional[Callable[[List[str]], None]] = None) -> None:
+        s, d, D, L, B = self.s, self.d, self.D, self.L, self.B
+        M = B * L
+        bf = self.bufs
+        d_raw = bf.get("d_raw", (B, D), BF16)
+        ops.l2norm_bwd(d_f.contiguous().float(), self.f, bf.get("inv", (B,), F32), d_raw, B, D)
+        pooled = bf.get("pooled", (B, d), BF16)
+        d_pooled = bf.get("d_pooled", (B, d), BF16)
+        ops.gemm(ops.NT, ops.EPI_BF16, d_raw, s.copies["text_projection"].wb, d_pooled, M=B, N=d, K=D)
+        ops.gemm(ops.TN, ops.EPI_F32, pooled, d_raw, s.g("text_projection"), M=d, N=D, K=B)
+        dxe = bf.get("dx_eot", (B, d), F32)
+        last = self.t.layers - 1
+        ops.layernorm_bwd(d_pooled, bf.get("x_eot", (B, d), F32), bf.get("m_post", (B,), F32),
+                          bf.get("r_post", (B,), F32), s.p("ln_final.weight"), dxe, None, s.g("ln_final.weight"),
+                          s.g("ln_final.bias"), s.g(f"transformer.resblocks.{last}.mlp.c_proj.bias"), B, d,
+                          accumulate=False)
+        dres = bf.get("dres", (M, d), F32)
+        dres_bf = bf.get("dres_bf", (M, d), BF16)
+        dres.zero_()
+        dres_bf.zero_()
+        ops.scatter_rows(dxe, bf.get("eot", (B,), torch.int32), L, dres, dres_bf, B, d)
+        if on_bucket is not None:
+            on_bucket(self.param_names_head())
+        cb = (lambda i: on_bucket(self.stack.layer_param_names(i))) if on_bucket is not None else None
+        self.stack.backward(dres, dres_bf, last_bias_colsum_done=True, on_layer_done=cb)
+        ops.token_embed_bwd(self.text, dres, s.g("token_embedding.weight"), s.g("positional_embedding"), B, L, d, self.V)
+        if on_bucket is not None:
+            on_bucket(self.param_names_stem())
