@@ -11,6 +11,7 @@
 // of C; they are then bounced through LDS once so that global stores / residual loads are full
 // 128..256-byte row segments.
 #include "sc_gemm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 
     // ---------------- epilogue: bounce the wave's 64x64 tile through LDS ----------------
+    EpiRegs<EPI> er;
+    sc_epi_load<EPI>(er, m0 + wm * 64, n0 + wn * 64, lane, g);
     float* ep = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): a wave only reads back its own region
     __builtin_amdgcn_wave_barrier();
 
-    sc_epilogue_store<EPI>(ep, m0 + wm * 64, n0 + wn * 64, lane, g, z);
+    sc_epilogue_store<EPI>(ep, er, m0 + wm * 64, n0 + wn * 64, lane, g, z);
 }
 
 __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab,
@@ -213,7 +216,15 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
     g.aux = (const bf16*)aux; g.ldaux = ldaux;
-    const int took = sc_gemm256_try(mode, epi, g, splitk, slabs, (float*)C, st);
+    // kernel choice: default 256x256 LDS-DMA kernel -> 128x128 general kernel; SC_GEMM_FORCE = 128 | 256 | p3 pins
+    // one kernel for A/B benchmarking (p3 = the 256x128 3-stage two-workgroups-per-CU variant, measured slower).
+    static const char* force = getenv("SC_GEMM_FORCE");
+    int took = 0;
+    if (force && force[0] == 'p') took = sc_gemm_p3_try(mode, epi, g, splitk, slabs, st);
+    if (took == 0 && (!force || force[0] == '2')) {
+        g.C = C;
+        took = sc_gemm256_try(mode, epi, g, splitk, slabs, (float*)C, st);
+    }
     if (took < 0) return took;
     if (took == 1) {
         splitk = g.splitk;

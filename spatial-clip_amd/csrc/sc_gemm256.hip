@@ -125,6 +125,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 
     // ---------------- epilogue: two 64-row halves of the wave's 128x64 tile through a private LDS region ----------------
     float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
+    EpiRegs<EPI> er;
+    sc_epi_load<EPI>(er, m0 + wm * 128, n0 + wn * 64, lane, g);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             for (int j = 0; j < 4; ++j) sc_epi_put(ep, i, j, li, lg, acc[h * 4 + i][j]);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
-        sc_epilogue_store<EPI>(ep, m0 + wm * 128 + h * 64, n0 + wn * 64, lane, g, z);
+        sc_epilogue_store<EPI>(ep, er, m0 + wm * 128 + h * 64, n0 + wn * 64, lane, g, z,
+                               h == 0 ? m0 + wm * 128 + 64 : -1);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
@@ -156,8 +159,6 @@ int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
 
 int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, float* c_final, hipStream_t st) {
     // eligibility: enough work for 256-tiles, K a multiple of 64 per split, inner dims allow clamped 16-byte chunks
-    static const char* force = getenv("SC_GEMM_FORCE");      // "128": always the general kernel (A/B benchmarking)
-    if (force && force[0] == '1') return 0;
     if (g.M < 256 || g.N < 192 || (g.K % BK) != 0) return 0;
     if (mode == SC_GEMM_TN && ((g.M % 8) != 0 || (g.N % 8) != 0)) return 0;
     const long long work = (long long)g.M * g.N;

@@ -1,5 +1,11 @@
-// Shared pieces of the two MFMA GEMM kernels (128x128 general kernel in sc_gemm.hip, 256x256 LDS-DMA kernel in
-// sc_gemm256.hip): argument block and the fused epilogue that drains a wave's 64x64 fp32 tile from LDS.
+// Shared pieces of the MFMA GEMM kernels (128x128 general kernel in sc_gemm.hip, 256x256 LDS-DMA kernel in
+// sc_gemm256.hip, 256x128 3-stage kernel in sc_gemm_p3.hip): argument block and the fused epilogue that drains a
+// wave's 64x64 fp32 tile from LDS.
+//
+// Epilogue memory-level parallelism: the extra epilogue INPUT of a 64x64 sub-tile (fp32 residual rows, or the bf16
+// pre-GELU tensor for GELU') is fetched by ONE burst of loads into registers (sc_epi_load) before the accumulators
+// take their trip through LDS, and the registers are refilled for the next sub-tile as they are consumed -- a wave
+// keeps 8-16 KiB in flight instead of waiting for HBM once per row group.
 #pragma once
 #include "sc_common.h"
 #include "sc_kernels.h"
@@ -26,32 +32,89 @@ struct GemmArgs {
 
 constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes and reads)
 
+// exact-erf GELU to 1.5e-7 (Abramowitz-Stegun 7.1.26) sharing one exp between erf and the Gaussian pdf:
+//   e = exp(-x^2/2);  erf(|x|/sqrt2) = 1 - poly(t) * e,  t = 1/(1 + p |x|/sqrt2)
+SC_DEVICE void sc_gelu_parts(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float e = __expf(-ax * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    pdf = 0.3989422804014327f * e;
+}
+SC_DEVICE float sc_gelu_fast(float x) {
+    float c, p;
+    sc_gelu_parts(x, c, p);
+    return x * c;
+}
+SC_DEVICE float sc_gelu_grad_fast(float x) {
+    float c, p;
+    sc_gelu_parts(x, c, p);
+    return c + x * p;
+}
+
 // Stage one MFMA accumulator block (swapped orientation: lane owns C[m = li][n = 4*lg .. +3]) into the wave's LDS tile
 SC_DEVICE void sc_epi_put(float* ep, int row16, int col16, int li, int lg, f32x4 acc) {
     *reinterpret_cast<f32x4*>(ep + (row16 * 16 + li) * SC_EPI_LD + col16 * 16 + lg * 4) = acc;
 }
 
-// Drain a wave-private 64x64 fp32 tile (row stride SC_EPI_LD) to global memory with full-row-segment accesses.
 template <int EPI>
-SC_DEVICE void sc_epilogue_store(const float* ep, int gm0, int gn0, int lane, const GemmArgs& g, int z) {
+struct EpiRegs {
+    static constexpr bool kRes = (EPI == SC_EPI_F32_BIAS_RES);
+    static constexpr bool kAux = (EPI == SC_EPI_BF16_DGELU);
+    f32x4 r[kRes ? 16 : 1];
+    bf16x8 a[kAux ? 8 : 1];
+};
+
+// issue the loads of the epilogue input of the 64x64 sub-tile at (gm0, gn0)
+template <int EPI>
+SC_DEVICE void sc_epi_load(EpiRegs<EPI>& e, int gm0, int gn0, int lane, const GemmArgs& g) {
+    if (EPI == SC_EPI_F32_BIAS_RES) {
+        const int gn = gn0 + (lane & 15) * 4;
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const int gm = gm0 + ps * 4 + (lane >> 4);
+            e.r[ps] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (g.res && gm < g.M && gn < g.N) e.r[ps] = *reinterpret_cast<const f32x4*>(g.res + (size_t)gm * g.ldres + gn);
+        }
+    }
+    if (EPI == SC_EPI_BF16_DGELU) {
+        const int gn = gn0 + (lane & 7) * 8;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int gm = gm0 + ps * 8 + (lane >> 3);
+            if (gm < g.M && gn < g.N) e.a[ps] = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm * g.ldaux + gn);
+        }
+    }
+}
+
+// Drain a wave-private 64x64 fp32 tile (row stride SC_EPI_LD) to global memory with full-row-segment accesses.
+// If next_gm0 >= 0 the input registers are refilled for the sub-tile at (next_gm0, gn0) as they are consumed.
+template <int EPI>
+SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int gn0, int lane, const GemmArgs& g, int z,
+                                 int next_gm0 = -1) {
     if (EPI == SC_EPI_F32 || EPI == SC_EPI_F32_BIAS_RES) {
         float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.slab_stride;
         const int col = (lane & 15) * 4;
         const int gn = gn0 + col;
         f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (EPI == SC_EPI_F32_BIAS_RES && g.bias && gn < g.N) bv = *reinterpret_cast<const f32x4*>(g.bias + gn);
-#pragma unroll 4
+#pragma unroll
         for (int ps = 0; ps < 16; ++ps) {
             const int row = ps * 4 + (lane >> 4);
             const int gm = gm0 + row;
-            if (gm < g.M && gn < g.N) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * SC_EPI_LD + col);
-                if (EPI == SC_EPI_F32_BIAS_RES) {
-                    v += bv;
-                    if (g.res) v += *reinterpret_cast<const f32x4*>(g.res + (size_t)gm * g.ldres + gn);
+            f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * SC_EPI_LD + col);
+            if (EPI == SC_EPI_F32_BIAS_RES) {
+                v += bv + e.r[ps];
+                if (next_gm0 >= 0) {
+                    const int gm2 = next_gm0 + row;
+                    e.r[ps] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (g.res && gm2 < g.M && gn < g.N)
+                        e.r[ps] = *reinterpret_cast<const f32x4*>(g.res + (size_t)gm2 * g.ldres + gn);
                 }
-                *reinterpret_cast<f32x4*>(C + (size_t)gm * g.ldc + gn) = v;
             }
+            if (gm < g.M && gn < g.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * g.ldc + gn) = v;
         }
     } else {
         bf16* C = reinterpret_cast<bf16*>(g.C);
@@ -59,36 +122,40 @@ SC_DEVICE void sc_epilogue_store(const float* ep, int gm0, int gn0, int lane, co
         const int gn = gn0 + col;
         float bv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+        for (int k = 0; k < 8; ++k) bv[k] = 0.f;
         if ((EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) && g.bias && gn < g.N) {
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + gn);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias + gn + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+            for (int k = 0; k < 4; ++k) { bv[k] = b0[k]; bv[4 + k] = b1[k]; }
         }
-#pragma unroll 4
+#pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int row = ps * 8 + (lane >> 3);
             const int gm = gm0 + row;
-            if (gm < g.M && gn < g.N) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * SC_EPI_LD + col);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + row * SC_EPI_LD + col + 4);
-                float v[8];
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * SC_EPI_LD + col);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + row * SC_EPI_LD + col + 4);
+            float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bv[e]; v[4 + e] = v1[e] + bv[4 + e]; }
-                if (EPI == SC_EPI_BF16_DGELU) {
-                    const bf16x8 u = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm * g.ldaux + gn);
+            for (int k = 0; k < 4; ++k) { v[k] = v0[k] + bv[k]; v[4 + k] = v1[k] + bv[4 + k]; }
+            if (EPI == SC_EPI_BF16_DGELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= sc_gelu_grad((float)u[e]);
+                for (int k = 0; k < 8; ++k) v[k] *= sc_gelu_grad_fast((float)e.a[ps][k]);
+                if (next_gm0 >= 0) {
+                    const int gm2 = next_gm0 + row;
+                    if (gm2 < g.M && gn < g.N)
+                        e.a[ps] = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm2 * g.ldaux + gn);
                 }
+            }
+            if (gm < g.M && gn < g.N) {
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
                 *reinterpret_cast<bf16x8*>(C + (size_t)gm * g.ldc + gn) = o;
                 if (EPI == SC_EPI_GELU_PAIR) {
                     bf16x8 h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = (bf16)sc_gelu((float)o[e]);
+                    for (int k = 0; k < 8; ++k) h[k] = (bf16)sc_gelu_fast((float)o[k]);
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.C2) + (size_t)gm * g.ldc2 + gn) = h;
                 }
             }
@@ -98,3 +165,5 @@ SC_DEVICE void sc_epilogue_store(const float* ep, int gm0, int gn0, int lane, co
 
 // 256x256 LDS-DMA kernel (sc_gemm256.hip): returns 1 if it took the problem, 0 if not eligible, <0 on error
 int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, float* c_final, hipStream_t st);
+// 256x128x32 3-stage kernel, two workgroups per CU (sc_gemm_p3.hip): same contract
+int sc_gemm_p3_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
