@@ -21,6 +21,7 @@ SC_DEVICE void stbf4(bf16* p, f32x4 v) {
 }
 
 // ------------------------------------------------------------------ LayerNorm forward
+template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      bf16* __restrict__ y, long long ldy, float* __restrict__ mean,
@@ -30,10 +31,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (row >= rows) return;
     const float* xr = x + (long long)row * ldx;
     const int nv = d >> 2;
-    f32x4 v[MAXV];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
         if (e < nv) {
             v[i] = ld4(xr + e * 4);
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float mu = sc_wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
         if (e < nv) {
 #pragma unroll
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
     bf16* yr = y + (long long)row * ldy;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
         if (e < nv) {
             const f32x4 g = ld4(gamma + e * 4), b = ld4(beta + e * 4);
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ------------------------------------------------------------------ LayerNorm backward
 // dres_new = (accumulate ? dres : 0) + LNbwd(dy); also emits the bf16 copy of dres_new (the A operand of
 // the next dgrad / wgrad GEMMs) and per-block partials of dgamma, dbeta and colsum(dres_new).
+template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
-    f32x4 ag[MAXV], ab[MAXV], ac[MAXV], gm[MAXV];
+    f32x4 ag[NV], ab[NV], ac[NV], gm[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         ag[i] = ab[i] = ac[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int e = i * 64 + lane;
         gm[i] = e < nv ? ld4(gamma + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         const float mu = mean[row], rs = rstd[row];
         const bf16* dyr = dy + (long long)row * lddy;
         const float* xr = x + (long long)row * ldx;
-        f32x4 g[MAXV], xh[MAXV];
+        f32x4 g[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int e = i * 64 + lane;
             if (e < nv) {
                 const f32x4 dyv = ldbf4(dyr + e * 4);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         float* dr = dres + (long long)row * lddres;
         bf16* db = dres_bf ? dres_bf + (long long)row * lddbf : nullptr;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int e = i * 64 + lane;
             if (e < nv) {
                 f32x4 o = accumulate ? ld4(dr + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     // block reduce of the 3 column vectors: smem[wave][3][d]
     float* sm = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
         if (e < nv) {
             st4(sm + (wave * 3 + 0) * d + e * 4, ag[i]);
@@ -149,20 +151,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 }
 
 // out_k[c] = sum_b partial[b][k][c], k = 0..nvec-1 ; outputs may be null
-// block = 64 columns x 4 partial groups (fixed summation order -> deterministic)
-__global__ __launch_bounds__(256) void colvec_finalize_kernel(const float* __restrict__ partial, int nblk, int nvec,
-                                                              int d, float* __restrict__ o0, float* __restrict__ o1,
-                                                              float* __restrict__ o2) {
-    __shared__ float sm[4][64];
+// block = 64 columns x 16 partial groups (fixed summation order -> deterministic)
+__global__ __launch_bounds__(1024) void colvec_finalize_kernel(const float* __restrict__ partial, int nblk, int nvec,
+                                                               int d, float* __restrict__ o0, float* __restrict__ o1,
+                                                               float* __restrict__ o2) {
+    __shared__ float sm[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + tx;
     float s = 0.f;
     if (e < nvec * d)
-        for (int b = ty; b < nblk; b += 4) s += partial[(long long)b * nvec * d + e];
+        for (int b = ty; b < nblk; b += 16) s += partial[(long long)b * nvec * d + e];
     sm[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && e < nvec * d) {
-        s = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sm[k][tx];
         const int k = e / d, c = e - k * d;
         float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
         if (o) o[c] = s;
@@ -265,15 +269,18 @@ extern "C" int sc_layernorm_fwd(const float* x, long long ldx, const float* gamm
                                 long long ldy, float* mean, float* rstd, int rows, int d, float eps, void* stream) {
     SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_fwd: bad shape rows=%d d=%d", rows, d);
     SC_CHECK((ldx % 4) == 0 && (ldy % 4) == 0, "sc_layernorm_fwd: row strides must be multiples of 4");
-    ln_fwd_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows,
-                                                                  d, eps);
+    const int nvv = (d / 4 + 63) / 64;
+#define SC_LN_FWD(NV) ln_fwd_kernel<NV><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps)
+    if (nvv <= 1) SC_LN_FWD(1); else if (nvv == 2) SC_LN_FWD(2); else if (nvv == 3) SC_LN_FWD(3);
+    else if (nvv == 4) SC_LN_FWD(4); else SC_LN_FWD(8);
+#undef SC_LN_FWD
     SC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
     int nblk = (rows + 3) / 4;
-    if (nblk > 256) nblk = 256;
+    if (nblk > 1024) nblk = 1024;
     return (long long)nblk * 3 * d;
 }
 
@@ -284,17 +291,23 @@ extern "C" int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, 
     SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_bwd: bad shape rows=%d d=%d", rows, d);
     SC_CHECK(ws != nullptr, "sc_layernorm_bwd: workspace required");
     int nblk = (rows + 3) / 4;
-    if (nblk > 256) nblk = 256;
+    if (nblk > 1024) nblk = 1024;
     const size_t lds = (size_t)4 * 3 * d * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    ln_bwd_kernel<<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres,
-                                          (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate);
+    const int nvv = (d / 4 + 63) / 64;
+#define SC_LN_BWD(NV)                                                                                              \
+    do {                                                                                                           \
+        if (lds > 48 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NV>),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        ln_bwd_kernel<NV><<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres,  \
+                                                  (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate);               \
+    } while (0)
+    if (nvv <= 1) SC_LN_BWD(1); else if (nvv == 2) SC_LN_BWD(2); else if (nvv == 3) SC_LN_BWD(3);
+    else if (nvv == 4) SC_LN_BWD(4); else SC_LN_BWD(8);
+#undef SC_LN_BWD
     SC_LAUNCH_CHECK();
-    colvec_finalize_kernel<<<(3 * d + 63) / 64, 256, 0, st>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
+    colvec_finalize_kernel<<<(3 * d + 63) / 64, 1024, 0, st>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -314,7 +327,7 @@ extern "C" int sc_colsum_bf16(const void* x, long long ld, int rows, int n, floa
     dim3 grid((n + 255) / 256, ny);
     colsum_kernel<<<grid, 256, 0, st>>>((const bf16*)x, ld, rows, n, ws);
     SC_LAUNCH_CHECK();
-    colvec_finalize_kernel<<<(n + 63) / 64, 256, 0, st>>>(ws, ny, 1, n, out, nullptr, nullptr);
+    colvec_finalize_kernel<<<(n + 63) / 64, 1024, 0, st>>>(ws, ny, 1, n, out, nullptr, nullptr);
     SC_LAUNCH_CHECK();
     return 0;
 }

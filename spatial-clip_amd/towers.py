@@ -11,6 +11,7 @@ Residual stream fp32, GEMM operands bf16 with fp32 accumulation, LayerNorm / sof
 the reference's ``precision: bf16-mixed`` autocast policy."""
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -107,54 +108,104 @@ class TransformerStack:
     # -------------------------------------------------------------------------------- backward
     def backward(self, dres: torch.Tensor, dres_bf: torch.Tensor, last_bias_colsum_done: bool,
                  on_layer_done: Optional[Callable[[int], None]] = None) -> None:
-        """``dres`` (fp32) / ``dres_bf`` (bf16 copy) hold dL/d(output of the last block) on entry and
+        """``dres`` (fp32) / ``dres_bf`` (bf16 copy) hold dL/d(output of the last block) on entry; ``dres`` holds
         dL/d(input of block 0) on exit.  ``last_bias_colsum_done``: the caller already wrote the last block's
-        c_proj.bias gradient (column sum of dres)."""
+        c_proj.bias gradient (column sum of dres).
+
+        Two HIP streams: the data-gradient chain (dgrad GEMMs, attention backward, LayerNorm backward) is the critical
+        path on the caller's stream; weight-gradient GEMMs and bias column sums only feed the optimiser, so they run on
+        a side stream and fill the tail rounds / memory-bound phases of the chain.  Buffers a side kernel reads
+        (bf16 residual gradient, dU, dqkv) rotate, and the chain waits on the side stream's event before reusing one."""
         s, d, H, dh, mlp = self.s, self.d, self.H, self.dh, self.mlp
         B, L, M = self.B, self.L, self.M
         bf = self.bufs
-        dU = bf.get("dU", (M, mlp), BF16)
+        overlap = os.environ.get("SC_OVERLAP", "1") != "0"
+        main = torch.cuda.current_stream()
+        if overlap and getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        side = self._side if overlap else main
+        last_read = {}                                   # buffer id -> event recorded on the side stream
+
+        def on_side(fn, reads) -> None:
+            """Run fn on the side stream after everything enqueued on main so far; remember what it reads."""
+            if not overlap:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                fn()
+                done = torch.cuda.Event()
+                done.record(side)
+            for t in reads:
+                last_read[t.data_ptr()] = done
+
+        def before_write(t: torch.Tensor) -> None:
+            ev = last_read.pop(t.data_ptr(), None)
+            if ev is not None:
+                main.wait_event(ev)
+
         dA = bf.get("dA", (M, d), BF16)
         dO = bf.get("dO", (M, d), BF16)
-        dqkv = bf.get("dqkv", (M, 3 * d), BF16)
         delta = bf.get("delta", (B, H, L), F32)
+        ring = [dres_bf, bf.get("dres_bf.1", (M, d), BF16), bf.get("dres_bf.2", (M, d), BF16)]
+        rpos = 0
         for i in reversed(range(self.layers)):
-            g = lambda leaf: s.g(self._n(i, leaf))
-            cp = lambda leaf: s.copies[self._n(i, leaf)]
+            g = lambda leaf, i=i: s.g(self._n(i, leaf))
+            cp = lambda leaf, i=i: s.copies[self._n(i, leaf)]
             a1, qkv, o = bf.get(f"a1.{i}", (M, d), BF16), bf.get(f"qkv.{i}", (M, 3 * d), BF16), bf.get(f"o.{i}", (M, d), BF16)
             a2, u, h = bf.get(f"a2.{i}", (M, d), BF16), bf.get(f"u.{i}", (M, mlp), BF16), bf.get(f"h.{i}", (M, mlp), BF16)
             xmid = bf.get(f"xmid.{i}", (M, d), F32)
             lse = bf.get(f"lse.{i}", (B, H, L), F32)
+            dU = bf.get(f"dU.{i & 1}", (M, mlp), BF16)
+            dqkv = bf.get(f"dqkv.{i & 1}", (M, 3 * d), BF16)
+            g0 = ring[rpos]
             if i == self.layers - 1 and not last_bias_colsum_done:
-                ops.colsum_bf16(dres_bf, M, d, g("mlp.c_proj.bias"))
+                ops.colsum_bf16(g0, M, d, g("mlp.c_proj.bias"))
             # ---- MLP branch: x_out = xmid + c_proj(gelu(c_fc(ln_2(xmid))))
-            ops.gemm(ops.NT, ops.EPI_BF16_DGELU, dres_bf, cp("mlp.c_proj.weight").wb, dU, M=M, N=mlp, K=d, aux=u)
-            ops.gemm(ops.TN, ops.EPI_F32, dres_bf, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M,
-                     splitk=_splitk_for(d, mlp, M))
+            before_write(dU)
+            ops.gemm(ops.NT, ops.EPI_BF16_DGELU, g0, cp("mlp.c_proj.weight").wb, dU, M=M, N=mlp, K=d, aux=u)
+
+            def w_mlp(g0=g0, h=h, dU=dU, a2=a2, g=g):
+                ops.gemm(ops.TN, ops.EPI_F32, g0, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M, splitk=_splitk_for(d, mlp, M))
+                ops.gemm(ops.TN, ops.EPI_F32, dU, a2, g("mlp.c_fc.weight"), M=mlp, N=d, K=M, splitk=_splitk_for(mlp, d, M))
+                ops.colsum_bf16(dU, M, mlp, g("mlp.c_fc.bias"))
+            on_side(w_mlp, (g0, dU))
             ops.gemm(ops.NT, ops.EPI_BF16, dU, cp("mlp.c_fc.weight").wb, dA, M=M, N=d, K=mlp)
-            ops.gemm(ops.TN, ops.EPI_F32, dU, a2, g("mlp.c_fc.weight"), M=mlp, N=d, K=M, splitk=_splitk_for(mlp, d, M))
-            ops.colsum_bf16(dU, M, mlp, g("mlp.c_fc.bias"))
             # LN2 backward accumulates into the residual gradient; its column sum is out_proj.bias' gradient
+            rpos = (rpos + 1) % 3
+            g1 = ring[rpos]
+            before_write(g1)
             ops.layernorm_bwd(dA, xmid, bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32),
-                              s.p(self._n(i, "ln_2.weight")), dres, dres_bf, g("ln_2.weight"), g("ln_2.bias"),
+                              s.p(self._n(i, "ln_2.weight")), dres, g1, g("ln_2.weight"), g("ln_2.bias"),
                               g("attn.out_proj.bias"), M, d, accumulate=True)
             # ---- attention branch: xmid = x_in + out_proj(attn(in_proj(ln_1(x_in))))
-            ops.gemm(ops.NT, ops.EPI_BF16, dres_bf, cp("attn.out_proj.weight").wb, dO, M=M, N=d, K=d)
-            ops.gemm(ops.TN, ops.EPI_F32, dres_bf, o, g("attn.out_proj.weight"), M=d, N=d, K=M,
-                     splitk=_splitk_for(d, d, M))
+            ops.gemm(ops.NT, ops.EPI_BF16, g1, cp("attn.out_proj.weight").wb, dO, M=M, N=d, K=d)
+            before_write(dqkv)
             ops.attn_bwd(qkv, o, dO, lse, B, L, H, dh, self.causal, dqkv=dqkv, delta=delta)
+
+            def w_attn(g1=g1, o=o, dqkv=dqkv, a1=a1, g=g):
+                ops.gemm(ops.TN, ops.EPI_F32, g1, o, g("attn.out_proj.weight"), M=d, N=d, K=M, splitk=_splitk_for(d, d, M))
+                ops.gemm(ops.TN, ops.EPI_F32, dqkv, a1, g("attn.in_proj_weight"), M=3 * d, N=d, K=M,
+                         splitk=_splitk_for(3 * d, d, M))
+                ops.colsum_bf16(dqkv, M, 3 * d, g("attn.in_proj_bias"))
+            on_side(w_attn, (g1, dqkv))
             ops.gemm(ops.NT, ops.EPI_BF16, dqkv, cp("attn.in_proj_weight").wb, dA, M=M, N=d, K=3 * d)
-            ops.gemm(ops.TN, ops.EPI_F32, dqkv, a1, g("attn.in_proj_weight"), M=3 * d, N=d, K=M,
-                     splitk=_splitk_for(3 * d, d, M))
-            ops.colsum_bf16(dqkv, M, 3 * d, g("attn.in_proj_bias"))
             # LN1 backward; its column sum is the previous block's c_proj.bias gradient
             prev_bias = s.g(self._n(i - 1, "mlp.c_proj.bias")) if i > 0 else None
+            rpos = (rpos + 1) % 3
+            g2 = ring[rpos]
+            before_write(g2)
             ops.layernorm_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
-                              s.p(self._n(i, "ln_1.weight")), dres, dres_bf, g("ln_1.weight"), g("ln_1.bias"),
+                              s.p(self._n(i, "ln_1.weight")), dres, g2, g("ln_1.weight"), g("ln_1.bias"),
                               prev_bias, M, d, accumulate=True)
             if on_layer_done is not None:
-                on_layer_done(i)
-
+                on_side(lambda i=i: on_layer_done(i), ())     # the bucket all-reduce follows the side stream
+        if overlap:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
 
 class VisionTower:
     """VisionTransformer (pool 'tok', learnable pos-embed, ln_pre/ln_post, output projection) + L2 normalise."""
