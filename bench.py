@@ -75,6 +75,21 @@ def cpu_baseline(model_name: str, n_genes: int, B: int = 8, steps: int = 3):
             "sample": f"oracle fp32 train step ({model_name}, n_genes={n_genes}), B={B}, 1 warm-up + {steps} timed steps, best"}
 
 
+def pmc_traffic_nt():
+    """HBM bytes per NT-GEMM launch from the committed rocprofv3 PMC passes (profiles/README.md); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    tot = n = 0
+    for k, v in d.items():
+        if "gemm256_kernel<0," in k:
+            tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
+            n += v["launches"]
+    return round(tot / n) if n else None
+
+
 def note(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench +{time.time() - T0:.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -188,9 +203,9 @@ def main():
         dom = "gemm_nt"
         fl, sec, cnt = agg[dom]
         ach = fl / sec / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel<NT> (forward + dgrad GEMMs)", "achieved": round(ach, 1),
+        roofline = {"bound": "mfma", "kernel": "gemm256_kernel<NT> (forward + dgrad GEMMs)", "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": cnt // args.steps,
+                    "traffic": pmc_traffic_nt(), "launches_per_step": cnt // args.steps,
                     "avg_launch_us": round(sec / cnt * 1e6, 1), "flops_per_launch_avg": fl / cnt,
                     "share_of_step_time": round(sec / dt, 3)}
         if "gemm_tn" in agg:
