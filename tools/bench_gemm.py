@@ -46,18 +46,23 @@ def run(name, mode, epi, Mo, No, K, **kw):
     print(f"{name:28s} M={Mo:6d} N={No:5d} K={K:6d}  {us:8.1f} us  {2.0 * Mo * No * K / us / 1e6:7.1f} TF/s", flush=True)
 
 
-from spatial_clip_amd.towers import _splitk_for
-d, mlp = 768, 3072
-run("qkv fwd (bias)", ops.NT, ops.EPI_BF16_BIAS, M, 3 * d, d)
-run("out_proj fwd (res f32)", ops.NT, ops.EPI_F32_BIAS_RES, M, d, d)
-run("c_fc fwd (gelu pair)", ops.NT, ops.EPI_GELU_PAIR, M, mlp, d)
-run("c_proj fwd (res f32)", ops.NT, ops.EPI_F32_BIAS_RES, M, d, mlp)
-run("c_proj dgrad (dgelu)", ops.NT, ops.EPI_BF16_DGELU, M, mlp, d)
-run("c_fc dgrad", ops.NT, ops.EPI_BF16, M, d, mlp)
-run("out_proj dgrad", ops.NT, ops.EPI_BF16, M, d, d)
-run("qkv dgrad", ops.NT, ops.EPI_BF16, M, d, 3 * d)
-run("plain 4096^3", ops.NT, ops.EPI_BF16, 4096, 4096, 4096)
-run("c_proj wgrad", ops.TN, ops.EPI_F32, d, mlp, M, splitk=_splitk_for(d, mlp, M))
-run("c_fc wgrad", ops.TN, ops.EPI_F32, mlp, d, M, splitk=_splitk_for(mlp, d, M))
-run("out_proj wgrad", ops.TN, ops.EPI_F32, d, d, M, splitk=_splitk_for(d, d, M))
-run("qkv wgrad", ops.TN, ops.EPI_F32, 3 * d, d, M, splitk=_splitk_for(3 * d, d, M))
+def main():
+    from spatial_clip_amd.towers import _splitk_for
+    d, mlp = 768, 3072
+    run("qkv fwd (bias)", ops.NT, ops.EPI_BF16_BIAS, M, 3 * d, d)
+    run("out_proj fwd (res f32)", ops.NT, ops.EPI_F32_BIAS_RES, M, d, d)
+    run("c_fc fwd (gelu pair)", ops.NT, ops.EPI_GELU_PAIR, M, mlp, d)
+    run("c_proj fwd (res f32)", ops.NT, ops.EPI_F32_BIAS_RES, M, d, mlp)
+    run("c_proj dgrad (dgelu)", ops.NT, ops.EPI_BF16_DGELU, M, mlp, d)
+    run("c_fc dgrad", ops.NT, ops.EPI_BF16, M, d, mlp)
+    run("out_proj dgrad", ops.NT, ops.EPI_BF16, M, d, d)
+    run("qkv dgrad", ops.NT, ops.EPI_BF16, M, d, 3 * d)
+    run("plain 4096^3", ops.NT, ops.EPI_BF16, 4096, 4096, 4096)
+    run("c_proj wgrad", ops.TN, ops.EPI_F32, d, mlp, M, splitk=_splitk_for(d, mlp, M))
+    run("c_fc wgrad", ops.TN, ops.EPI_F32, mlp, d, M, splitk=_splitk_for(mlp, d, M))
+    run("out_proj wgrad", ops.TN, ops.EPI_F32, d, d, M, splitk=_splitk_for(d, d, M))
+    run("qkv wgrad", ops.TN, ops.EPI_F32, 3 * d, d, M, splitk=_splitk_for(3 * d, d, M))
+    
+
+if __name__ == "__main__":
+    main()
