@@ -4,7 +4,10 @@
 // GELU pair, GELU') whose HBM traffic is comparable to the main loop's MFMA time.  With one 139 KiB workgroup per CU
 // (sc_gemm256.hip) the epilogue of a tile cannot overlap anything.  Here a workgroup is 4 waves (2x2), each wave a
 // 128x64 tile = 8x4 MFMA 16x16x32 (128 accumulator VGPRs), LDS = 72 KiB (3 stages x (16 + 8) KiB), so two workgroups
-// share a CU and one's epilogue / barrier stalls hide under the other's MFMA stream.
+// share a CU.  MEASURED (round 1): this does NOT beat the 256x256 kernel on any tower shape (e.g. c_fc fwd 398 vs 361 us),
+// nor does running two such kernels on two streams, nor phase-staggering the co-resident workgroups by half a tile:
+// the serialised epilogue is not hidden by a second resident workgroup.  Kept selectable (SC_GEMM_FORCE=p3) as the
+// A/B baseline for the next step (in-wave software-pipelined epilogue of a persistent kernel).
 //   - operands by LDS-DMA (global_load_lds_dwordx4), prefetch distance 2, counted s_waitcnt vmcnt (never 0 in the
 //     steady state) + raw s_barrier: one barrier per 32-deep K step;
 //   - XOR swizzle on the DMA source address and on the fragment read (64-byte rows for NT, 512/256-byte rows for TN);
