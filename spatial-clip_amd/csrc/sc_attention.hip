@@ -36,7 +36,7 @@ struct Img {
 template <int DH>
 SC_DEVICE void load_image(char* img, const bf16* src, long long row_stride, int L, int Lp, int t) {
     constexpr int CH = DH / 8;
-    for (int c = t; c < Lp * CH; c += 256) {
+    for (int c = t; c < Lp * CH; c += blockDim.x) {
         const int row = c / CH, ch = c % CH;
         u32x4 v = (u32x4){0u, 0u, 0u, 0u};
         if (row < L) v = *reinterpret_cast<const u32x4*>(src + (long long)row * row_stride + ch * 8);
@@ -80,7 +80,7 @@ SC_DEVICE float quad_sum(float v) {
 
 // ---------------------------------------------------------------------------------------------- forward
 template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+__global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int L, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = DH / 32, DT = DH / 16;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     __syncthreads();
     const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
     const int nqt = (L + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += (blockDim.x >> 6)) {
         const int q = qt * 16 + li;           // this lane's query (B-operand column)
         const int qc = min(q, L - 1);
         bf16x8 qf[KS];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 
 // ---------------------------------------------------------------------------------------------- backward: dQ (+ delta)
 template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+__global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                              float* __restrict__ delta, bf16* __restrict__ dqkv, int L,
                                                              int H, float scale) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
     __syncthreads();
     const float c2 = scale * 1.4426950408889634f;
     const int nqt = (L + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += (blockDim.x >> 6)) {
         const int q = qt * 16 + li;
         const int qc = min(q, L - 1);
         bf16x8 qf[KS], dof[KS];
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 
 // ---------------------------------------------------------------------------------------------- backward: dK, dV
 template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv,
+__global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv,
                                                               const bf16* __restrict__ dout,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta, bf16* __restrict__ dqkv,
@@ -252,14 +252,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
     float* sdel = slse + Lp;
     load_image<DH>(Qimg, base, rs, L, Lp, t);
     load_image<DH>(Gimg, dout + (long long)b * L * d + h * DH, d, L, Lp, t);
-    for (int i = t; i < Lp; i += 256) {
+    for (int i = t; i < Lp; i += blockDim.x) {
         slse[i] = i < L ? -lse[((long long)b * H + h) * L + i] * 1.4426950408889634f : 0.f;
         sdel[i] = i < L ? delta[((long long)b * H + h) * L + i] : 0.f;
     }
     __syncthreads();
     const float c2 = scale * 1.4426950408889634f;
     const int nkt = (L + 15) >> 4;
-    for (int kt = wave; kt < nkt; kt += 4) {
+    for (int kt = wave; kt < nkt; kt += (blockDim.x >> 6)) {
         const int key = kt * 16 + li;  // this lane's key (B-operand column)
         const int kc = min(key, L - 1);
         bf16x8 kf[KS], vf[KS];
@@ -323,11 +323,18 @@ void set_lds(K kern, size_t bytes) {
 
 #define SC_ATTN_DISPATCH(KERNEL, ...)                                                         \
     do {                                                                                      \
-        if (dh == 64 && !causal) { set_lds(KERNEL<64, false>, lds); KERNEL<64, false><<<B * H, 256, lds, st>>>(__VA_ARGS__); } \
-        else if (dh == 64 && causal) { set_lds(KERNEL<64, true>, lds); KERNEL<64, true><<<B * H, 256, lds, st>>>(__VA_ARGS__); } \
-        else if (dh == 32 && !causal) { set_lds(KERNEL<32, false>, lds); KERNEL<32, false><<<B * H, 256, lds, st>>>(__VA_ARGS__); } \
-        else { set_lds(KERNEL<32, true>, lds); KERNEL<32, true><<<B * H, 256, lds, st>>>(__VA_ARGS__); } \
+        if (dh == 64 && !causal) { set_lds(KERNEL<64, false>, lds); KERNEL<64, false><<<B * H, nthreads, lds, st>>>(__VA_ARGS__); } \
+        else if (dh == 64 && causal) { set_lds(KERNEL<64, true>, lds); KERNEL<64, true><<<B * H, nthreads, lds, st>>>(__VA_ARGS__); } \
+        else if (dh == 32 && !causal) { set_lds(KERNEL<32, false>, lds); KERNEL<32, false><<<B * H, nthreads, lds, st>>>(__VA_ARGS__); } \
+        else { set_lds(KERNEL<32, true>, lds); KERNEL<32, true><<<B * H, nthreads, lds, st>>>(__VA_ARGS__); } \
     } while (0)
+
+// one wave per 16-row tile, all tiles of a head in flight at once when they fit (13 waves at L=197): balanced work
+static int attn_threads(int L) {
+    const int tiles = (L + 15) / 16;
+    const int rounds = (tiles + 12) / 13;
+    return ((tiles + rounds - 1) / rounds) * 64;
+}
 
 static int attn_check(const char* who, int B, int L, int H, int dh) {
     SC_CHECK(B > 0 && H > 0 && L > 0 && L <= MAXL, "%s: need 0 < L <= %d (L=%d), B=%d H=%d", who, MAXL, L, B, H);
@@ -342,6 +349,7 @@ extern "C" int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L,
     const int Lp = (L + 31) & ~31;
     const size_t lds = (size_t)2 * Lp * dh * 2;
     const float scale = 1.0f / sqrtf((float)dh);
+    const int nthreads = attn_threads(L);
     SC_ATTN_DISPATCH(attn_fwd_kernel, (const bf16*)qkv, (bf16*)out, lse, L, H, scale);
     SC_LAUNCH_CHECK();
     return 0;
@@ -353,6 +361,7 @@ extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, c
     hipStream_t st = (hipStream_t)stream;
     const int Lp = (L + 31) & ~31;
     const float scale = 1.0f / sqrtf((float)dh);
+    const int nthreads = attn_threads(L);
     {
         const size_t lds = (size_t)2 * Lp * dh * 2;
         SC_ATTN_DISPATCH(attn_bwd_dq_kernel, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta,
