@@ -49,7 +49,10 @@ SC_DEVICE void stage_tile(const GemmArgs& g, char* sA, char* sB, int m0, int n0,
     }
 }
 
-template <int MODE, int EPI>
+// NI = MFMA row-fragments per wave: 8 -> the workgroup owns a full 256-row tile; 4 / 2 -> it owns one half / quarter
+// of a tile (128 / 64 rows).  The split variants run the LAST, partially filled round of a launch: the remaining
+// tiles are cut so that every CU gets a (shorter) piece instead of most CUs idling for a whole tile time.
+template <int MODE, int EPI, int NI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
@@ -58,19 +61,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, lg = lane >> 4;
 
+    constexpr int MSPLIT = 8 / NI;
     int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
+    const int part = idx % MSPLIT;
+    idx = idx / MSPLIT + g.tile_offset;
     const int tn = idx % g.ntn;
     idx /= g.ntn;
     const int tm = idx % g.ntm;
     const int z = idx / g.ntm;
     const int m0 = tm * BM, n0 = tn * BN;
+    const int mw = part * (BM / MSPLIT) + wm * (16 * NI);      // this wave's first row inside the tile
     const int kbeg = z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nt = (kend - kbeg) / BK;
 
-    f32x4 acc[8][4];
+    f32x4 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -88,15 +95,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[8], bfr[4];
+            bf16x8 af[NI], bfr[4];
             if (MODE == SC_GEMM_NT) {
                 const int coff = ((kk * 4 + lg) ^ ((li >> 1) & 7)) << 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     bfr[j] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + j * 16 + li) * 128 + coff);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    af[i] = *reinterpret_cast<const bf16x8*>(sA + (wm * 128 + i * 16 + li) * 128 + coff);
+                for (int i = 0; i < NI; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(sA + (mw + i * 16 + li) * 128 + coff);
             } else {
                 const int q = li >> 2, p = li & 3;
                 const int kr = kk * 32 + lg * 8 + q;
@@ -107,14 +114,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
                     bfr[j] = sc_cat(sc_lds_tr16(pb), sc_lds_tr16(pb + 4 * 512));
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const char* pa = sA + kr * 512 + (((wm * 8 + i) ^ s) << 5) + p * 8;
+                for (int i = 0; i < NI; ++i) {
+                    const char* pa = sA + kr * 512 + ((((mw >> 4) + i) ^ s) << 5) + p * 8;
                     af[i] = sc_cat(sc_lds_tr16(pa), sc_lds_tr16(pa + 4 * 512));
                 }
             }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = sc_mfma16(bfr[j], af[i], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
@@ -125,34 +132,56 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 
     // ---------------- epilogue: two 64-row halves of the wave's 128x64 tile through a private LDS region ----------------
     float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
+    constexpr int NH = NI > 4 ? 2 : 1;               // 64-row passes of the wave's tile
+    constexpr int IH = NI > 4 ? 4 : NI;              // row-fragments per pass
     EpiRegs<EPI> er;
-    sc_epi_load<EPI>(er, m0 + wm * 128, n0 + wn * 64, lane, g);
+    sc_epi_load<EPI>(er, m0 + mw, n0 + wn * 64, lane, g, 16 * IH);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < IH; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sc_epi_put(ep, i, j, li, lg, acc[h * 4 + i][j]);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
-        sc_epilogue_store<EPI>(ep, er, m0 + wm * 128 + h * 64, n0 + wn * 64, lane, g, z,
-                               h == 0 ? m0 + wm * 128 + 64 : -1);
+        sc_epilogue_store<EPI>(ep, er, m0 + mw + h * 64, n0 + wn * 64, lane, g, z,
+                               (h + 1 < NH) ? m0 + mw + 64 : -1, 16 * IH);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <int MODE, int EPI>
-int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
+template <int MODE, int EPI, int NI>
+int launch1(const GemmArgs& g, int nblocks, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<MODE, EPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<MODE, EPI, NI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
     }
-    gemm256_kernel<MODE, EPI><<<nblocks, 512, LDS_BYTES, st>>>(g);
+    gemm256_kernel<MODE, EPI, NI><<<nblocks, 512, LDS_BYTES, st>>>(g);
     SC_LAUNCH_CHECK();
     return 1;
+}
+
+// full rounds with whole tiles, then the remainder cut into halves / quarters so that it still covers the chip
+template <int MODE, int EPI>
+int launch(GemmArgs& g, int ntiles, hipStream_t st) {
+    constexpr int CUS = 256;
+    static const bool tail_split = !(getenv("SC_GEMM_TAIL") && getenv("SC_GEMM_TAIL")[0] == '0');
+    const int rem = ntiles % CUS;
+    int msplit = 1;
+    if (tail_split && g.splitk == 1 && ntiles > CUS && rem > 0) {
+        if (rem * 4 <= CUS) msplit = 4;
+        else if (rem * 2 <= CUS + 64) msplit = 2;
+    }
+    g.tile_offset = 0;
+    if (msplit == 1) return launch1<MODE, EPI, 8>(g, ntiles, st);
+    const int nfull = ntiles - rem;
+    int rc = launch1<MODE, EPI, 8>(g, nfull, st);
+    if (rc != 1) return rc;
+    g.tile_offset = nfull;
+    return msplit == 4 ? launch1<MODE, EPI, 2>(g, rem * 4, st) : launch1<MODE, EPI, 4>(g, rem * 2, st);
 }
 
 }  // namespace

@@ -28,6 +28,7 @@ struct GemmArgs {
     int k_per_split;
     long long slab_stride;
     int ntm, ntn;
+    int tile_offset;      // first logical tile of this launch (tail launches of sc_gemm256)
 };
 
 constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes and reads)
@@ -69,14 +70,15 @@ struct EpiRegs {
 
 // issue the loads of the epilogue input of the 64x64 sub-tile at (gm0, gn0)
 template <int EPI>
-SC_DEVICE void sc_epi_load(EpiRegs<EPI>& e, int gm0, int gn0, int lane, const GemmArgs& g) {
+SC_DEVICE void sc_epi_load(EpiRegs<EPI>& e, int gm0, int gn0, int lane, const GemmArgs& g, int mrows = 64) {
+    const int mlim = min(g.M, gm0 + mrows);
     if (EPI == SC_EPI_F32_BIAS_RES) {
         const int gn = gn0 + (lane & 15) * 4;
 #pragma unroll
         for (int ps = 0; ps < 16; ++ps) {
             const int gm = gm0 + ps * 4 + (lane >> 4);
             e.r[ps] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (g.res && gm < g.M && gn < g.N) e.r[ps] = *reinterpret_cast<const f32x4*>(g.res + (size_t)gm * g.ldres + gn);
+            if (g.res && gm < mlim && gn < g.N) e.r[ps] = *reinterpret_cast<const f32x4*>(g.res + (size_t)gm * g.ldres + gn);
         }
     }
     if (EPI == SC_EPI_BF16_DGELU) {
@@ -84,7 +86,7 @@ SC_DEVICE void sc_epi_load(EpiRegs<EPI>& e, int gm0, int gn0, int lane, const Ge
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int gm = gm0 + ps * 8 + (lane >> 3);
-            if (gm < g.M && gn < g.N) e.a[ps] = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm * g.ldaux + gn);
+            if (gm < mlim && gn < g.N) e.a[ps] = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm * g.ldaux + gn);
         }
     }
 }
@@ -93,7 +95,8 @@ SC_DEVICE void sc_epi_load(EpiRegs<EPI>& e, int gm0, int gn0, int lane, const Ge
 // If next_gm0 >= 0 the input registers are refilled for the sub-tile at (next_gm0, gn0) as they are consumed.
 template <int EPI>
 SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int gn0, int lane, const GemmArgs& g, int z,
-                                 int next_gm0 = -1) {
+                                 int next_gm0 = -1, int mrows = 64) {
+    const int mlim = min(g.M, gm0 + mrows);
     if (EPI == SC_EPI_F32 || EPI == SC_EPI_F32_BIAS_RES) {
         float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.slab_stride;
         const int col = (lane & 15) * 4;
@@ -114,7 +117,7 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
                         e.r[ps] = *reinterpret_cast<const f32x4*>(g.res + (size_t)gm2 * g.ldres + gn);
                 }
             }
-            if (gm < g.M && gn < g.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * g.ldc + gn) = v;
+            if (gm < mlim && gn < g.N) *reinterpret_cast<f32x4*>(C + (size_t)gm * g.ldc + gn) = v;
         }
     } else {
         bf16* C = reinterpret_cast<bf16*>(g.C);
@@ -147,7 +150,7 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
                         e.a[ps] = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm2 * g.ldaux + gn);
                 }
             }
-            if (gm < g.M && gn < g.N) {
+            if (gm < mlim && gn < g.N) {
                 bf16x8 o;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
