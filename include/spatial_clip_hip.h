@@ -49,10 +49,14 @@ long long sc_gemm_slab_floats(int M, int N, int K, int splitk);
  * columns h*dh): softmax(q k^T / sqrt(dh)) v, fp32 softmax, optional causal mask.  Replaces
  * nn.MultiheadAttention's SDPA core (src/open_clip/transformer.py:272-287; mask :1080-1086).
  * out[B*L, H*dh] bf16, lse[B,H,L] fp32 (log-sum-exp of the scaled scores, kept for backward).
- * sc_attn_bwd writes dqkv[B*L, 3*H*dh] (bf16) and uses delta[B,H,L] as scratch.  L <= 320, dh in {32, 64}. */
-int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dh, int causal, void* stream);
+ * sc_attn_bwd writes dqkv[B*L, 3*H*dh] (bf16) and uses delta[B,H,L] as scratch.  L <= 320, dh in {32, 64}.
+ * q_rows > 0 restricts the work to the first q_rows query positions of every sequence (the last ViT block only
+ * feeds the CLS token downstream): outputs / dq of the other rows are not written, dk / dv receive only those
+ * queries' contributions (dout of the unused rows is never read). */
+int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dh, int causal, int q_rows,
+                void* stream);
 int sc_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                int B, int L, int H, int dh, int causal, void* stream);
+                int B, int L, int H, int dh, int causal, int q_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * LayerNorm over the last dim of the fp32 residual stream (eps 1e-5; src/open_clip/transformer.py:23-29),

@@ -81,7 +81,7 @@ SC_DEVICE float quad_sum(float v) {
 // ---------------------------------------------------------------------------------------------- forward
 template <int DH, bool CAUSAL>
 __global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                          float* __restrict__ lse, int L, int H, float scale) {
+                                                          float* __restrict__ lse, int L, int Lq, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = DH / 32, DT = DH / 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16* __restrict__
     load_image<DH>(Vimg, base + 2 * d, rs, L, Lp, t);
     __syncthreads();
     const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
-    const int nqt = (L + 15) >> 4;
+    const int nqt = (Lq + 15) >> 4;        // only the first Lq query rows are needed
     for (int qt = wave; qt < nqt; qt += (blockDim.x >> 6)) {
         const int q = qt * 16 + li;           // this lane's query (B-operand column)
         const int qc = min(q, L - 1);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16* __restrict__
         }
         lsum = quad_sum(lsum);
         const float inv = 1.0f / lsum;
-        if (q < L) {
+        if (q < Lq) {
             bf16* orow = out + ((long long)b * L + q) * d + h * DH;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
@@ -161,7 +161,7 @@ template <int DH, bool CAUSAL>
 __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                              float* __restrict__ delta, bf16* __restrict__ dqkv, int L,
-                                                             int H, float scale) {
+                                                             int Lq, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = DH / 32, DT = DH / 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16* __restric
     load_image<DH>(Vimg, base + 2 * d, rs, L, Lp, t);
     __syncthreads();
     const float c2 = scale * 1.4426950408889634f;
-    const int nqt = (L + 15) >> 4;
+    const int nqt = (Lq + 15) >> 4;        // only the first Lq query rows are needed
     for (int qt = wave; qt < nqt; qt += (blockDim.x >> 6)) {
         const int q = qt * 16 + li;
         const int qc = min(q, L - 1);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16* __restric
         }
         dl = quad_sum(dl);
         const float nl2 = -lse[((long long)b * H + h) * L + qc] * 1.4426950408889634f;
-        if (q < L && lg == 0) delta[((long long)b * H + h) * L + q] = dl;
+        if (q < Lq && lg == 0) delta[((long long)b * H + h) * L + q] = dl;
         f32x4 dq[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16* __restric
             for (int dt = 0; dt < DT; ++dt)
                 dq[dt] = sc_mfma16(frag_tr<DH>(Kimg, k0, dt * 16, li, lg), dsf, dq[dt]);
         }
-        if (q < L) {
+        if (q < Lq) {
             bf16* drow = dqkv + ((long long)b * L + q) * rs + h * DH;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16* __restri
                                                               const bf16* __restrict__ dout,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                              int L, int H, float scale) {
+                                                              int L, int Lq, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = DH / 32, DT = DH / 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16* __restri
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int qbeg = CAUSAL ? ((kt * 16) / 32) * 32 : 0;
-        for (int q0 = qbeg; q0 < Lp; q0 += 32) {
+        for (int q0 = qbeg; q0 < ((Lq + 31) & ~31); q0 += 32) {
             // S[q][key], dP[q][key]: rows = queries 4g+r (+16), col = key
             f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
 #pragma unroll
@@ -286,12 +286,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16* __restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qa = q0 + 4 * lg + r, qb = qa + 16;
-                const float pa = (qa >= L || key >= L || (CAUSAL && key > qa)) ? 0.f : exp2f(s0[r] * c2 + slse[qa]);
-                const float pb = (qb >= L || key >= L || (CAUSAL && key > qb)) ? 0.f : exp2f(s1[r] * c2 + slse[qb]);
+                // masked entries are forced to exact zeros (lse / delta of unused query rows may hold anything)
+                const bool ma = (qa >= Lq || key >= L || (CAUSAL && key > qa));
+                const bool mb = (qb >= Lq || key >= L || (CAUSAL && key > qb));
+                const float pa = ma ? 0.f : exp2f(s0[r] * c2 + slse[qa]);
+                const float pb = mb ? 0.f : exp2f(s1[r] * c2 + slse[qb]);
                 pr0[r] = pa;
                 pr1[r] = pb;
-                s0[r] = pa * (p0[r] - sdel[qa]);
-                s1[r] = pb * (p1[r] - sdel[qb]);
+                s0[r] = ma ? 0.f : pa * (p0[r] - sdel[qa]);
+                s1[r] = mb ? 0.f : pb * (p1[r] - sdel[qb]);
             }
             const bf16x8 pf = pack8(pr0, pr1), dsf = pack8(s0, s1);
 #pragma unroll
@@ -343,21 +346,23 @@ static int attn_check(const char* who, int B, int L, int H, int dh) {
 }
 
 extern "C" int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dh, int causal,
-                           void* stream) {
+                           int q_rows, void* stream) {
     if (attn_check("sc_attn_fwd", B, L, H, dh)) return -1;
+    const int Lq = (q_rows > 0 && q_rows < L) ? q_rows : L;
     hipStream_t st = (hipStream_t)stream;
     const int Lp = (L + 31) & ~31;
     const size_t lds = (size_t)2 * Lp * dh * 2;
     const float scale = 1.0f / sqrtf((float)dh);
     const int nthreads = attn_threads(L);
-    SC_ATTN_DISPATCH(attn_fwd_kernel, (const bf16*)qkv, (bf16*)out, lse, L, H, scale);
+    SC_ATTN_DISPATCH(attn_fwd_kernel, (const bf16*)qkv, (bf16*)out, lse, L, Lq, H, scale);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
-                           void* dqkv, int B, int L, int H, int dh, int causal, void* stream) {
+                           void* dqkv, int B, int L, int H, int dh, int causal, int q_rows, void* stream) {
     if (attn_check("sc_attn_bwd", B, L, H, dh)) return -1;
+    const int Lq = (q_rows > 0 && q_rows < L) ? q_rows : L;
     hipStream_t st = (hipStream_t)stream;
     const int Lp = (L + 31) & ~31;
     const float scale = 1.0f / sqrtf((float)dh);
@@ -365,12 +370,12 @@ extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, c
     {
         const size_t lds = (size_t)2 * Lp * dh * 2;
         SC_ATTN_DISPATCH(attn_bwd_dq_kernel, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta,
-                         (bf16*)dqkv, L, H, scale);
+                         (bf16*)dqkv, L, Lq, H, scale);
         SC_LAUNCH_CHECK();
     }
     {
         const size_t lds = (size_t)2 * Lp * dh * 2 + (size_t)2 * Lp * 4;
-        SC_ATTN_DISPATCH(attn_bwd_dkv_kernel, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, L, H,
+        SC_ATTN_DISPATCH(attn_bwd_dkv_kernel, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, L, Lq, H,
                          scale);
         SC_LAUNCH_CHECK();
     }

@@ -94,19 +94,19 @@ def workspace(nfloat: int, device, tag: str = "ws", dtype=torch.float32) -> torc
 
 # ------------------------------------------------------------------------------------------ attention
 def attn_fwd(qkv: torch.Tensor, B: int, L: int, H: int, dh: int, causal: bool = False,
-             out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None):
+             out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None, q_rows: int = 0):
     _req(qkv, torch.bfloat16, "qkv")
     if out is None:
         out = torch.empty((B * L, H * dh), dtype=torch.bfloat16, device=qkv.device)
     if lse is None:
         lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
-    check(_lib.lib().sc_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, L, H, dh, int(causal), _stream()),
-          "sc_attn_fwd")
+    check(_lib.lib().sc_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, L, H, dh, int(causal), q_rows,
+                                 _stream()), "sc_attn_fwd")
     return out, lse
 
 
 def attn_bwd(qkv, out, dout, lse, B: int, L: int, H: int, dh: int, causal: bool = False,
-             dqkv: Optional[torch.Tensor] = None, delta: Optional[torch.Tensor] = None):
+             dqkv: Optional[torch.Tensor] = None, delta: Optional[torch.Tensor] = None, q_rows: int = 0):
     for t_, n in ((qkv, "qkv"), (out, "out"), (dout, "dout")):
         _req(t_, torch.bfloat16, n)
     if dqkv is None:
@@ -114,7 +114,7 @@ def attn_bwd(qkv, out, dout, lse, B: int, L: int, H: int, dh: int, causal: bool 
     if delta is None:
         delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
     check(_lib.lib().sc_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                 dqkv.data_ptr(), B, L, H, dh, int(causal), _stream()), "sc_attn_bwd")
+                                 dqkv.data_ptr(), B, L, H, dh, int(causal), q_rows, _stream()), "sc_attn_bwd")
     return dqkv
 
 

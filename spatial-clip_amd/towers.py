@@ -53,7 +53,12 @@ class _Bufs:
 class TransformerStack:
     """N pre-LN residual attention blocks (ResidualAttentionBlock, transformer.py:238-300)."""
 
-    def __init__(self, store: ParamStore, prefix: str, width: int, heads: int, layers: int, mlp: int, causal: bool):
+    def __init__(self, store: ParamStore, prefix: str, width: int, heads: int, layers: int, mlp: int, causal: bool,
+                 cls_only_last: bool = False):
+        # cls_only_last: only token 0 of the last block's output is consumed downstream (ViT pool 'tok'), so that
+        # block computes K/V for all tokens but attention output, out_proj and the MLP for the CLS rows only -- the
+        # values the reference would compute for the other 196 rows are dead.
+        self.cls_only_last = cls_only_last and os.environ.get("SC_CLS_ONLY", "1") != "0"
         self.s, self.prefix = store, prefix
         self.d, self.H, self.layers, self.mlp, self.causal = width, heads, layers, mlp, causal
         self.dh = width // heads
@@ -87,6 +92,8 @@ class TransformerStack:
                      M=M, N=3 * d, K=d, bias=s.p(self._n(i, "attn.in_proj_bias")))
             o = bf.get(f"o.{i}", (M, d), BF16)
             lse = bf.get(f"lse.{i}", (B, H, L), F32)
+            if self.cls_only_last and i == self.layers - 1:
+                return self._forward_last_cls(i, x, qkv, o, lse)
             ops.attn_fwd(qkv, B, L, H, dh, self.causal, out=o, lse=lse)
             xmid = bf.get(f"xmid.{i}", (M, d), F32)
             ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, o, s.copies[self._n(i, "attn.out_proj.weight")].wf, xmid,
@@ -104,6 +111,81 @@ class TransformerStack:
                      M=M, N=d, K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
             x = xo
         return x
+
+    def _forward_last_cls(self, i: int, x: torch.Tensor, qkv: torch.Tensor, o: torch.Tensor, lse: torch.Tensor):
+        """Last block, CLS rows only (compact [B, d] tensors; the CLS rows of full tensors are strided views)."""
+        s, d, H, dh, mlp, B, L = self.s, self.d, self.H, self.dh, self.mlp, self.B, self.L
+        bf = self.bufs
+        ops.attn_fwd(qkv, B, L, H, dh, self.causal, out=o, lse=lse, q_rows=1)
+        o_c = o.view(B, L * d)[:, :d]
+        x_c = x.view(B, L * d)[:, :d]
+        xmid = bf.get("c.xmid", (B, d), F32)
+        ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, o_c, s.copies[self._n(i, "attn.out_proj.weight")].wf, xmid,
+                 M=B, N=d, K=d, bias=s.p(self._n(i, "attn.out_proj.bias")), res=x_c)
+        a2 = bf.get("c.a2", (B, d), BF16)
+        ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
+                          bf.get("c.m2", (B,), F32), bf.get("c.r2", (B,), F32), B, d)
+        u, h = bf.get("c.u", (B, mlp), BF16), bf.get("c.h", (B, mlp), BF16)
+        ops.gemm(ops.NT, ops.EPI_GELU_PAIR, a2, s.copies[self._n(i, "mlp.c_fc.weight")].wf, u, M=B, N=mlp, K=d,
+                 bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)
+        xo = bf.get("c.xout", (B, d), F32)
+        ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, h, s.copies[self._n(i, "mlp.c_proj.weight")].wf, xo, M=B, N=d, K=mlp,
+                 bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
+        return xo
+
+    def _backward_last_cls(self, dres_c: torch.Tensor, dres_c_bf: torch.Tensor, on_side) -> tuple:
+        """Backward of the CLS-only last block.  In: compact dL/d(x_out[CLS]) (fp32 + bf16).  Out: full fp32 / bf16
+        residual-gradient buffers holding dL/d(block input)."""
+        s, d, H, dh, mlp, B, L, M = self.s, self.d, self.H, self.dh, self.mlp, self.B, self.L, self.M
+        bf = self.bufs
+        i = self.layers - 1
+        g = lambda leaf: s.g(self._n(i, leaf))
+        cp = lambda leaf: s.copies[self._n(i, leaf)]
+        a1, qkv, o = bf.get(f"a1.{i}", (M, d), BF16), bf.get(f"qkv.{i}", (M, 3 * d), BF16), bf.get(f"o.{i}", (M, d), BF16)
+        lse = bf.get(f"lse.{i}", (B, H, L), F32)
+        a2, u, h, xmid = bf.get("c.a2", (B, d), BF16), bf.get("c.u", (B, mlp), BF16), bf.get("c.h", (B, mlp), BF16), \
+            bf.get("c.xmid", (B, d), F32)
+        dU = bf.get("c.dU", (B, mlp), BF16)
+        dA_c = bf.get("c.dA", (B, d), BF16)
+        ops.gemm(ops.NT, ops.EPI_BF16_DGELU, dres_c_bf, cp("mlp.c_proj.weight").wb, dU, M=B, N=mlp, K=d, aux=u)
+
+        def w_mlp():
+            ops.gemm(ops.TN, ops.EPI_F32, dres_c_bf, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=B)
+            ops.gemm(ops.TN, ops.EPI_F32, dU, a2, g("mlp.c_fc.weight"), M=mlp, N=d, K=B)
+            ops.colsum_bf16(dU, B, mlp, g("mlp.c_fc.bias"))
+        on_side(w_mlp, ())
+        ops.gemm(ops.NT, ops.EPI_BF16, dU, cp("mlp.c_fc.weight").wb, dA_c, M=B, N=d, K=mlp)
+        g1_c = bf.get("c.dres_bf1", (B, d), BF16)
+        ops.layernorm_bwd(dA_c, xmid, bf.get("c.m2", (B,), F32), bf.get("c.r2", (B,), F32),
+                          s.p(self._n(i, "ln_2.weight")), dres_c, g1_c, g("ln_2.weight"), g("ln_2.bias"),
+                          g("attn.out_proj.bias"), B, d, accumulate=True)
+        # attention branch: dO is non-zero on the CLS rows only (written through a strided view of a zeroed buffer)
+        dO = bf.get("dO", (M, d), BF16)
+        dO.zero_()
+        ops.gemm(ops.NT, ops.EPI_BF16, g1_c, cp("attn.out_proj.weight").wb, dO.view(B, L * d)[:, :d], M=B, N=d, K=d)
+        o_c = o.view(B, L * d)[:, :d]
+        dqkv = bf.get(f"dqkv.{i & 1}", (M, 3 * d), BF16)
+        dqkv.zero_()
+        ops.attn_bwd(qkv, o, dO, lse, B, L, H, dh, self.causal, dqkv=dqkv, delta=bf.get("delta", (B, H, L), F32),
+                     q_rows=1)
+
+        def w_attn():
+            ops.gemm(ops.TN, ops.EPI_F32, g1_c, o_c, g("attn.out_proj.weight"), M=d, N=d, K=B)
+            ops.gemm(ops.TN, ops.EPI_F32, dqkv, a1, g("attn.in_proj_weight"), M=3 * d, N=d, K=M,
+                     splitk=_splitk_for(3 * d, d, M))
+            ops.colsum_bf16(dqkv, M, 3 * d, g("attn.in_proj_bias"))
+        on_side(w_attn, (dqkv,))
+        dA = bf.get("dA", (M, d), BF16)
+        ops.gemm(ops.NT, ops.EPI_BF16, dqkv, cp("attn.in_proj_weight").wb, dA, M=M, N=d, K=3 * d)
+        dres = bf.get("dres_full", (M, d), F32)
+        dres.zero_()
+        dres.view(B, L * d)[:, :d].copy_(dres_c)                   # the residual path of the CLS rows
+        dres_bf = bf.get("dres_bf.0", (M, d), BF16)
+        prev_bias = s.g(self._n(i - 1, "mlp.c_proj.bias")) if i > 0 else None
+        ops.layernorm_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
+                          s.p(self._n(i, "ln_1.weight")), dres, dres_bf, g("ln_1.weight"), g("ln_1.bias"),
+                          prev_bias, M, d, accumulate=True)
+        return dres, dres_bf
 
     # -------------------------------------------------------------------------------- backward
     def backward(self, dres: torch.Tensor, dres_bf: torch.Tensor, last_bias_colsum_done: bool,
@@ -149,9 +231,15 @@ class TransformerStack:
         dA = bf.get("dA", (M, d), BF16)
         dO = bf.get("dO", (M, d), BF16)
         delta = bf.get("delta", (B, H, L), F32)
+        top = self.layers
+        if self.cls_only_last:
+            dres, dres_bf = self._backward_last_cls(dres, dres_bf, on_side)
+            top = self.layers - 1
+            if on_layer_done is not None:
+                on_side(lambda: on_layer_done(self.layers - 1), ())
         ring = [dres_bf, bf.get("dres_bf.1", (M, d), BF16), bf.get("dres_bf.2", (M, d), BF16)]
         rpos = 0
-        for i in reversed(range(self.layers)):
+        for i in reversed(range(top)):
             g = lambda leaf, i=i: s.g(self._n(i, leaf))
             cp = lambda leaf, i=i: s.copies[self._n(i, leaf)]
             a1, qkv, o = bf.get(f"a1.{i}", (M, d), BF16), bf.get(f"qkv.{i}", (M, 3 * d), BF16), bf.get(f"o.{i}", (M, d), BF16)
@@ -206,6 +294,7 @@ class TransformerStack:
             ev = torch.cuda.Event()
             ev.record(side)
             main.wait_event(ev)
+        return dres
 
 class VisionTower:
     """VisionTransformer (pool 'tok', learnable pos-embed, ln_pre/ln_post, output projection) + L2 normalise."""
@@ -217,7 +306,7 @@ class VisionTower:
         self.kp = 3 * v.patch_size * v.patch_size
         self.kp_pad = store.copies["visual.conv1.weight"].k_pad
         self.stack = TransformerStack(store, "visual.transformer.resblocks.", v.width, v.heads, v.layers,
-                                      int(v.width * v.mlp_ratio), causal=False)
+                                      int(v.width * v.mlp_ratio), causal=False, cls_only_last=True)
         self.bufs = _Bufs(store.device)
 
     def param_names_head(self) -> List[str]:
@@ -250,8 +339,9 @@ class VisionTower:
         xf = self.stack.forward(x0, B, L)
         self.xf = xf
         pooled = bf.get("pooled", (B, d), BF16)
+        self.x_ld = d if self.stack.cls_only_last else L * d          # xf is compact [B, d] in CLS-only mode
         ops.layernorm_fwd(xf, s.p("visual.ln_post.weight"), s.p("visual.ln_post.bias"), pooled,
-                          bf.get("m_post", (B,), F32), bf.get("r_post", (B,), F32), B, d, ldx=L * d)
+                          bf.get("m_post", (B,), F32), bf.get("r_post", (B,), F32), B, d, ldx=self.x_ld)
         f_raw = bf.get("f_raw", (B, D), F32)
         ops.gemm(ops.NT, ops.EPI_F32, pooled, s.copies["visual.proj"].wf, f_raw, M=B, N=D, K=d)
         f = torch.empty((B, D), dtype=F32, device=images.device)
@@ -270,19 +360,25 @@ class VisionTower:
         cp = s.copies["visual.proj"]
         ops.gemm(ops.NT, ops.EPI_BF16, d_raw, cp.wb, d_pooled, M=B, N=d, K=D)
         ops.gemm(ops.TN, ops.EPI_F32, pooled, d_raw, s.g("visual.proj"), M=d, N=D, K=B)
-        dres = bf.get("dres", (M, d), F32)
-        dres_bf = bf.get("dres_bf", (M, d), BF16)
-        dres.zero_()
-        dres_bf.zero_()
         last = self.v.layers - 1
+        if self.stack.cls_only_last:
+            dres = bf.get("dres_c", (B, d), F32)
+            dres_bf = bf.get("dres_c_bf", (B, d), BF16)
+            ld = d
+        else:
+            dres = bf.get("dres", (M, d), F32)
+            dres_bf = bf.get("dres_bf", (M, d), BF16)
+            dres.zero_()
+            dres_bf.zero_()
+            ld = L * d
         ops.layernorm_bwd(d_pooled, self.xf, bf.get("m_post", (B,), F32), bf.get("r_post", (B,), F32),
                           s.p("visual.ln_post.weight"), dres, dres_bf, s.g("visual.ln_post.weight"),
                           s.g("visual.ln_post.bias"), s.g(f"visual.transformer.resblocks.{last}.mlp.c_proj.bias"),
-                          B, d, accumulate=False, ldx=L * d, lddres=L * d, lddbf=L * d)
+                          B, d, accumulate=False, ldx=self.x_ld, lddres=ld, lddbf=ld)
         if on_bucket is not None:
             on_bucket(self.param_names_head())
         cb = (lambda i: on_bucket(self.stack.layer_param_names(i))) if on_bucket is not None else None
-        self.stack.backward(dres, dres_bf, last_bias_colsum_done=True, on_layer_done=cb)
+        dres = self.stack.backward(dres, dres_bf, last_bias_colsum_done=True, on_layer_done=cb)
         # stem: ln_pre / positional / class embedding / conv1 (no gradient flows to the pixels)
         dpatch = bf.get("dpatch", (Mp, d), BF16)
         ops.embed_ln_bwd(dres, bf.get("patch_out", (Mp, d), F32), s.p("visual.class_embedding"),
