@@ -43,6 +43,12 @@ int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const void* B, int l
                  void* C, int ldc, void* C2, int ldc2, const float* bias, const float* res, int ldres,
                  const void* aux, int ldaux, int splitk, float* slabs, void* stream);
 long long sc_gemm_slab_floats(int M, int N, int K, int splitk);
+/* Weight AND bias gradient of one Linear in one pass: dW[M,N](f32) = dY[K,M]^T . X[K,N], dbias[M] = column sums of dY
+ * (fused into the TN kernel: the sums are taken from the MFMA fragments already in registers).
+ * ws: sc_gemm_wgrad_ws_floats() floats. */
+long long sc_gemm_wgrad_ws_floats(int M, int N, int K, int splitk);
+int sc_gemm_wgrad_bias(const void* dY, int lddy, const void* X, int ldx, int M, int N, int K, float* dW, int ldw,
+                       float* dbias, int splitk, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ attention
  * Fused multi-head self-attention on the packed in_proj output qkv[B*L, 3*H*dh] (q | k | v, head h at

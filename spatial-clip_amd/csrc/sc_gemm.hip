@@ -168,12 +168,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 }
 
 __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab,
-                                    long long slab_stride, long long n4) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (long long)gridDim.x * blockDim.x) {
-        f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
-        for (int z = 1; z < nslab; ++z) s += reinterpret_cast<const f32x4*>(slabs + z * slab_stride)[i];
-        reinterpret_cast<f32x4*>(out)[i] = s;
+                                    long long slab_stride, long long n4, float* __restrict__ cs_out,
+                                    const float* __restrict__ cs_part, int cs_n) {
+    if (slabs != nullptr) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+             i += (long long)gridDim.x * blockDim.x) {
+            f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
+            for (int z = 1; z < nslab; ++z) s += reinterpret_cast<const f32x4*>(slabs + z * slab_stride)[i];
+            reinterpret_cast<f32x4*>(out)[i] = s;
+        }
+    }
+    if (cs_out != nullptr) {        // partial column sums of the fused bias gradient: [nslab][cs_n] -> [cs_n]
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cs_n; i += gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int z = 0; z < nslab; ++z) s += cs_part[(long long)z * cs_n + i];
+            cs_out[i] = s;
+        }
     }
 }
 
@@ -216,6 +226,7 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
     g.aux = (const bf16*)aux; g.ldaux = ldaux;
+    g.colsum = nullptr; g.tile_offset = 0;
     // kernel choice: default 256x256 LDS-DMA kernel -> 128x128 general kernel; SC_GEMM_FORCE = 128 | 256 | p3 pins
     // one kernel for A/B benchmarking (p3 = the 256x128 3-stage two-workgroups-per-CU variant, measured slower).
     static const char* force = getenv("SC_GEMM_FORCE");
@@ -232,7 +243,7 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
             const long long n4 = (long long)M * N / 4;
             int blocks = (int)((n4 + 255) / 256);
             if (blocks > 2048) blocks = 2048;
-            reduce_slabs_kernel<<<blocks, 256, 0, st>>>((float*)C, slabs, splitk, g.slab_stride, n4);
+            reduce_slabs_kernel<<<blocks, 256, 0, st>>>((float*)C, slabs, splitk, g.slab_stride, n4, nullptr, nullptr, 0);
             SC_LAUNCH_CHECK();
         }
         return 0;
@@ -268,7 +279,7 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
         const long long n4 = (long long)M * N / 4;
         int blocks = (int)((n4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        reduce_slabs_kernel<<<blocks, 256, 0, st>>>((float*)C, slabs, splitk, g.slab_stride, n4);
+        reduce_slabs_kernel<<<blocks, 256, 0, st>>>((float*)C, slabs, splitk, g.slab_stride, n4, nullptr, nullptr, 0);
         SC_LAUNCH_CHECK();
     }
     return 0;
@@ -279,4 +290,49 @@ extern "C" long long sc_gemm_slab_floats(int M, int N, int K, int splitk) {
     if (splitk < 1) splitk = 1;
     if (splitk > ktiles) splitk = ktiles;
     return splitk > 1 ? (long long)splitk * M * N : 0;
+}
+
+
+// Weight gradient + bias gradient of one Linear in one pass: dW[M,N] = dY[K,M]^T . X[K,N] (fp32) and
+// dbias[M] = column sums of dY, fused into the TN kernel when the 256x256 kernel takes the problem.
+extern "C" long long sc_gemm_wgrad_ws_floats(int M, int N, int K, int splitk) {
+    long long a = sc_gemm_slab_floats(M, N, K, splitk);
+    int sk = splitk < 1 ? 1 : splitk;
+    long long b = (long long)sk * M + sc_colsum_ws_floats(K, M);
+    return a + b + 64;
+}
+
+extern "C" int sc_gemm_wgrad_bias(const void* dY, int lddy, const void* X, int ldx, int M, int N, int K, float* dW,
+                                  int ldw, float* dbias, int splitk, float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SC_CHECK(M > 0 && N > 0 && K > 0 && (M % 4) == 0 && (N % 4) == 0, "sc_gemm_wgrad_bias: bad shape M=%d N=%d K=%d", M, N, K);
+    SC_CHECK(ws != nullptr && dbias != nullptr, "sc_gemm_wgrad_bias: workspace / dbias required");
+    static const char* force = getenv("SC_GEMM_FORCE");
+    if (splitk < 1) splitk = 1;
+    const long long slab_floats = sc_gemm_slab_floats(M, N, K, splitk);
+    float* slabs = ws;
+    float* cs_part = ws + ((slab_floats + 15) / 16) * 16;
+    GemmArgs g;
+    g.A = (const bf16*)dY; g.B = (const bf16*)X; g.M = M; g.N = N; g.K = K; g.lda = lddy; g.ldb = ldx;
+    g.C = dW; g.ldc = ldw; g.C2 = nullptr; g.ldc2 = 0; g.bias = nullptr; g.res = nullptr; g.ldres = 0;
+    g.aux = nullptr; g.ldaux = 0; g.tile_offset = 0;
+    g.colsum = cs_part;
+    int took = 0;
+    if (!force || force[0] == '2') took = sc_gemm256_try(SC_GEMM_TN, SC_EPI_F32, g, splitk, slab_floats ? slabs : nullptr, dW, st);
+    if (took < 0) return took;
+    if (took == 1) {
+        const long long n4 = (long long)M * N / 4;
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < (M + 255) / 256) blocks = (M + 255) / 256;
+        reduce_slabs_kernel<<<blocks, 256, 0, st>>>(dW, g.splitk > 1 ? slabs : nullptr, g.splitk, g.slab_stride, n4, dbias,
+                                                    cs_part, M);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
+    // general path: separate GEMM and column-sum kernels
+    int rc = sc_gemm_bf16(SC_GEMM_TN, SC_EPI_F32, dY, lddy, X, ldx, M, N, K, dW, ldw, nullptr, 0, nullptr, nullptr, 0,
+                          nullptr, 0, slab_floats ? splitk : 1, slab_floats ? slabs : nullptr, stream);
+    if (rc != 0) return rc;
+    return sc_colsum_bf16(dY, lddy, K, M, dbias, cs_part, stream);
 }

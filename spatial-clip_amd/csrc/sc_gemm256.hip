@@ -81,6 +81,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // fused bias gradient of a weight-gradient GEMM: column sums of the At operand (dY) over this K range, taken
+    // from the fragments the wn == 0 waves of the tn == 0 workgroups read anyway (VALU work hidden under MFMA)
+    constexpr bool kColsum = (MODE == SC_GEMM_TN && EPI == SC_EPI_F32 && NI == 8);
+    const bool do_cs = kColsum && g.colsum != nullptr && tn == 0;
+    float cs[2] = {0.f, 0.f};          // each of the 4 wn-waves sums 2 of the 8 row-fragments (balanced VALU work)
+
     if (nt > 0) stage_tile<MODE>(g, smem, smem + TILE, m0, n0, kbeg, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -125,11 +131,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = sc_mfma16(bfr[j], af[i], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
+            if (kColsum && do_cs) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if ((i >> 1) == wn) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) cs[i & 1] += (float)af[i][e];
+                    }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
+    if (kColsum && do_cs) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float v = cs[k];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int m = m0 + mw + (2 * wn + k) * 16 + li;
+            if (lg == 0 && m < g.M) g.colsum[(size_t)z * g.M + m] = v;
+        }
+    }
     // ---------------- epilogue: two 64-row halves of the wave's 128x64 tile through a private LDS region ----------------
     float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
     constexpr int NH = NI > 4 ? 2 : 1;               // 64-row passes of the wave's tile
@@ -168,10 +192,12 @@ int launch1(const GemmArgs& g, int nblocks, hipStream_t st) {
 template <int MODE, int EPI>
 int launch(GemmArgs& g, int ntiles, hipStream_t st) {
     constexpr int CUS = 256;
-    static const bool tail_split = !(getenv("SC_GEMM_TAIL") && getenv("SC_GEMM_TAIL")[0] == '0');
+    // measured (interleaved A/B on one MI355X, ViT-B/16 step): splitting the last round is 0.4 ms/step SLOWER than
+    // leaving it whole -- workgroups are not in lockstep rounds, the hardware backfills; opt-in only (SC_GEMM_TAIL=1)
+    static const bool tail_split = (getenv("SC_GEMM_TAIL") && getenv("SC_GEMM_TAIL")[0] == '1');
     const int rem = ntiles % CUS;
     int msplit = 1;
-    if (tail_split && g.splitk == 1 && ntiles > CUS && rem > 0) {
+    if (tail_split && g.splitk == 1 && g.colsum == nullptr && ntiles > CUS && rem > 0) {
         if (rem * 4 <= CUS) msplit = 4;
         else if (rem * 2 <= CUS + 64) msplit = 2;
     }

@@ -29,6 +29,7 @@ struct GemmArgs {
     long long slab_stride;
     int ntm, ntn;
     int tile_offset;      // first logical tile of this launch (tail launches of sc_gemm256)
+    float* colsum;        // TN + EPI_F32 only: [splitk][M] partial column sums of the At operand (bias gradient), or null
 };
 
 constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes and reads)

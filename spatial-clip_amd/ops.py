@@ -75,6 +75,25 @@ def gemm(mode: int, epi: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tenso
     return out
 
 
+def gemm_wgrad_bias(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dbias: torch.Tensor, *, M: int, N: int, K: int,
+                    splitk: int = 1) -> None:
+    """dW[M,N] = dY[K,M]^T . X[K,N] (fp32) and dbias[M] = column sums of dY, one fused pass."""
+    _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw")
+    _req(dbias, torch.float32, "dbias")
+    l = _lib.lib()
+    ws = workspace(l.sc_gemm_wgrad_ws_floats(M, N, K, splitk), dw.device, "wgrad")
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    rc = l.sc_gemm_wgrad_bias(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K, dw.data_ptr(),
+                              dw.stride(0), dbias.data_ptr(), splitk, ws.data_ptr(), _stream())
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append(("gemm_tn", 2.0 * M * N * K, ev))
+    check(rc, "sc_gemm_wgrad_bias")
+
+
 # bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream
 KERNEL_EVENTS = None
 

@@ -98,3 +98,16 @@ def test_tn_asymmetric_exact():
     o32 = torch.empty((M, N), dtype=torch.float32, device="cuda")
     ops.gemm(ops.TN, ops.EPI_F32, at.to(torch.bfloat16).cuda(), bt.cuda(), o32, M=M, N=N, K=K)
     assert torch.equal(o32.cpu(), at.t() @ bt.float())
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(768, 768, 2048, 8), (3072, 768, 1024, 4), (2304, 768, 197 * 8, 2),
+                                          (512, 200, 256, 1), (768, 3072, 256, 1)])
+def test_wgrad_with_fused_bias_grad(M, N, K, splitk):
+    ops = _ops()
+    g = torch.Generator().manual_seed(K + M)
+    dy, x = _rand((K, M), g), _rand((K, N), g)
+    dw = torch.full((M, N), 9.0, dtype=torch.float32, device="cuda")
+    db = torch.full((M,), 9.0, dtype=torch.float32, device="cuda")
+    ops.gemm_wgrad_bias(dy.cuda(), x.cuda(), dw, db, M=M, N=N, K=K, splitk=splitk)
+    torch.testing.assert_close(dw.cpu(), dy.float().t() @ x.float(), atol=2e-3 * max(1, K ** 0.5 / 8), rtol=2e-3)
+    torch.testing.assert_close(db.cpu(), dy.float().sum(0), atol=2e-3 * max(1, K ** 0.5 / 8), rtol=1e-4)

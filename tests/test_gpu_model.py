@@ -227,3 +227,35 @@ def test_reference_three_training_steps_text_tower(golden_dir):
         assert abs(float(nc[0]) - float(z["grad_norms"][step])) < 0.05 * float(z["grad_norms"][step])
     for k in ("visual.proj", "text_projection", "token_embedding.weight", "visual.conv1.weight"):
         assert float((n.store.p(k).cpu() - z["p3." + k]).abs().max()) < 3e-3, k
+
+
+def test_vit_l14_shapes_vs_oracle():
+    """BASELINE.json configs[4] geometry (ViT-L/14: patch 14 -> K padding 588->640, L = 257, d = 1024, 16 heads) with a
+    shortened depth so that the CPU oracle stays fast: features, loss and a few gradients."""
+    data, losses, mc, module, net, optim = _pkg()
+    cfg = mc.get_model_config("ViT-L-14-gene", n_genes=512)
+    cfg.vision.layers = 2
+    v = cfg.vision
+    ocfg = O.ModelCfg(cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
+                      O.GeneCfg(512, cfg.gene.hidden))
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=4)
+    perturb(n)
+    params = {k: v_.cpu() for k, v_ in n.state_dict().items()}
+    batch = data.synthetic_batch(6, 224, 512, K=4)
+    torch.set_num_threads(16)
+    p = {k: v_.clone().requires_grad_(True) for k, v_ in params.items()}
+    f = O.net_forward(batch["images"], batch["texts"], p, ocfg)
+    ref = O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"])
+    ref.backward()
+    m = module.SpatialClipLitModule(n, losses.ClipLoss(local_loss=True, gather_with_grad=True), None, None)
+    out = m.model_step({k: v_.cuda() for k, v_ in batch.items()})
+    assert (out["image_features"].cpu() - f["image_features"].detach()).abs().max() < 5e-3
+    assert abs(float(out["loss"].detach()) - float(ref.detach())) < 4e-3
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    for k in ("visual.conv1.weight", "visual.positional_embedding", "visual.transformer.resblocks.0.attn.in_proj_weight",
+              "visual.transformer.resblocks.1.mlp.c_fc.weight", "visual.proj", "visual.ln_pre.weight"):
+        g_ref = p[k].grad.double()
+        g = n.store.g(k).cpu().double()
+        rel = float((g - g_ref).norm() / g_ref.norm().clamp_min(1e-12))
+        assert rel < 0.05, (k, rel)
