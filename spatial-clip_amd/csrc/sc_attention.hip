@@ -80,7 +80,7 @@ SC_DEVICE float quad_sum(float v) {
 
 // ---------------------------------------------------------------------------------------------- forward
 template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(1024) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int L, int Lq, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = DH / 32, DT = DH / 16;
@@ -333,9 +333,11 @@ void set_lds(K kern, size_t bytes) {
     } while (0)
 
 // one wave per 16-row tile, all tiles of a head in flight at once when they fit (13 waves at L=197): balanced work
-static int attn_threads(int L) {
+// max_waves: 13 for forward (68 VGPRs -> 7 waves/SIMD, two 13-wave workgroups per CU so that one workgroup's K/V load
+// overlaps the other's compute); 7 for backward (114-120 VGPRs -> 4 waves/SIMD: two 7-wave workgroups per CU)
+static int attn_threads(int L, int max_waves) {
     const int tiles = (L + 15) / 16;
-    const int rounds = (tiles + 12) / 13;
+    const int rounds = (tiles + max_waves - 1) / max_waves;
     return ((tiles + rounds - 1) / rounds) * 64;
 }
 
@@ -353,7 +355,7 @@ extern "C" int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L,
     const int Lp = (L + 31) & ~31;
     const size_t lds = (size_t)2 * Lp * dh * 2;
     const float scale = 1.0f / sqrtf((float)dh);
-    const int nthreads = attn_threads(L);
+    const int nthreads = attn_threads(L, 13);
     SC_ATTN_DISPATCH(attn_fwd_kernel, (const bf16*)qkv, (bf16*)out, lse, L, Lq, H, scale);
     SC_LAUNCH_CHECK();
     return 0;
@@ -366,7 +368,7 @@ extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, c
     hipStream_t st = (hipStream_t)stream;
     const int Lp = (L + 31) & ~31;
     const float scale = 1.0f / sqrtf((float)dh);
-    const int nthreads = attn_threads(L);
+    const int nthreads = attn_threads(L, 7);
     {
         const size_t lds = (size_t)2 * Lp * dh * 2;
         SC_ATTN_DISPATCH(attn_bwd_dq_kernel, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta,
