@@ -223,7 +223,7 @@ def main():
         if "gemm_tn" in agg:
             fl2, sec2, cnt2 = agg["gemm_tn"]
             roofline["wgrad_tn"] = {"achieved": round(fl2 / sec2 / 1e12, 1), "share_of_step_time": round(sec2 / dt_inst, 3),
-                                    "note": "runs on the side stream concurrently with the dgrad chain"}
+                                    "note": "weight-gradient GEMMs (split-K slabs + fused bias-gradient column sums)"}
         step_tflops = value / world * fpp / 1e12
         roofline["whole_step"] = {"achieved": round(step_tflops, 1), "frac": round(step_tflops / PEAK_BF16_TFLOPS, 4),
                                   "flops_per_pair": fpp}

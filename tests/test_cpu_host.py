@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
     l = _lib.lib()
     rc = l.sc_gemm_bf16(0, 0, None, 8, None, 8, 0, 8, 64, None, 8, None, 0, None, None, 0, None, 0, 1, None, None)
     assert rc < 0 and b"empty problem" in l.sc_last_error()
-    rc = l.sc_attn_fwd(None, None, None, 1, 1000, 1, 64, 0, None)
+    rc = l.sc_attn_fwd(None, None, None, 1, 1000, 1, 64, 0, 0, None)
     assert rc < 0 and b"L <=" in l.sc_last_error()
     rc = l.sc_layernorm_fwd(None, 6, None, None, None, 6, None, None, 4, 6, 1e-5, None)
     assert rc < 0
