@@ -232,6 +232,7 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     static const char* force = getenv("SC_GEMM_FORCE");
     int took = 0;
     if (force && force[0] == 'p') took = sc_gemm_p3_try(mode, epi, g, splitk, slabs, st);
+    if (force && force[0] == 's') took = sc_gemm_s4_try(mode, epi, g, splitk, slabs, st);
     if (took == 0 && (!force || force[0] == '2')) {
         g.C = C;
         took = sc_gemm256_try(mode, epi, g, splitk, slabs, (float*)C, st);

@@ -171,3 +171,5 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
 int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, float* c_final, hipStream_t st);
 // 256x128x32 3-stage kernel, two workgroups per CU (sc_gemm_p3.hip): same contract
 int sc_gemm_p3_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
+// 256x256x32 4-stage ring variant (sc_gemm_s4.hip): same contract
+int sc_gemm_s4_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
