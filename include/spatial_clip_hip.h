@@ -92,6 +92,10 @@ int sc_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* 
 int sc_cast_pad_bf16(const float* src, long long ld_src, void* dst, long long ld_dst, int rows, int cols,
                      int cols_pad, void* stream);
 int sc_cast_transpose_bf16(const float* src, void* dst, int rows, int cols, long long ld_dst, void* stream);
+/* All transposed copies in ONE launch: desc[n][5] (device int64) = {src offset in floats from `master`, dst pointer,
+ * rows, cols, ld_dst}; tile_prefix[n+1] (device int32) = running count of 64x64 tiles. */
+int sc_cast_transpose_batched(const float* master, const long long* desc, const int* tile_prefix, int n,
+                              int total_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ patch embedding
  * VisionTransformer._embeds (src/open_clip/transformer.py:783-798): conv1 with kernel = stride = patch is a GEMM
@@ -153,12 +157,13 @@ int sc_exp_scalar_bwd(const float* y, const float* dy, float* dx, float mult, vo
  * clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (src/models/spatial_clip_module.py:138-158,
  * configs/optimizer/adamw.yaml, configs/trainer/default.yaml:19).  grad_scale = 1/world_size folds DDP's
  * gradient mean.  sc_grad_norm writes norm_clip_out[2] = {|g|*grad_scale, min(1, max_norm/(norm+1e-6))};
- * ws: 1024 doubles.  sc_adamw_step reads the clip coefficient from norm_clip[1] (NULL = no clipping). */
+ * ws: 1024 doubles.  sc_adamw_step reads the clip coefficient from norm_clip[1] (NULL = no clipping) and, if
+ * params_bf16 is given, also writes the bf16 mirror of the updated parameters (same flat layout). */
 int sc_grad_norm(const float* grads, long long n, float grad_scale, float max_norm, double* ws, float* norm_clip_out,
                  void* stream);
 int sc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                  const float* norm_clip, void* stream);
+                  const float* norm_clip, void* params_bf16, void* stream);
 
 #ifdef __cplusplus
 }

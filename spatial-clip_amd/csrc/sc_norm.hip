@@ -263,7 +263,47 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// one launch for every transposed bf16 weight copy: desc[i] = {src offset (floats), dst pointer, rows, cols, ld_dst},
+// tile_prefix[i] = first 64x64 tile of matrix i (tile_prefix[n] = total); block -> matrix by binary search
+__global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const float* __restrict__ master,
+                                                                     const long long* __restrict__ desc,
+                                                                     const int* __restrict__ tile_prefix, int n) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n;
+    const int b = blockIdx.x;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+    }
+    const long long* dsc = desc + (long long)lo * 5;
+    const float* src = master + dsc[0];
+    bf16* dst = reinterpret_cast<bf16*>(dsc[1]);
+    const int rows = (int)dsc[2], cols = (int)dsc[3];
+    const long long ldd = dsc[4];
+    const int tb = b - tile_prefix[lo];
+    const int tcols = (cols + 63) >> 6;
+    const int r0 = (tb / tcols) * 64, c0 = (tb % tcols) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(long long)c * ldd + r] = (bf16)tile[tx][i];
+    }
+}
+
 }  // namespace
+
+extern "C" int sc_cast_transpose_batched(const float* master, const long long* desc, const int* tile_prefix, int n,
+                                         int total_tiles, void* stream) {
+    SC_CHECK(n > 0 && total_tiles > 0, "sc_cast_transpose_batched: nothing to do");
+    cast_transpose_batched_kernel<<<total_tiles, 256, 0, (hipStream_t)stream>>>(master, desc, tile_prefix, n);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int sc_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, void* y,
                                 long long ldy, float* mean, float* rstd, int rows, int d, float eps, void* stream) {

@@ -44,7 +44,8 @@ __global__ void sumsq_final_kernel(const double* __restrict__ partial, int nblk,
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long long n,
                                                     float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt, float gscale, const float* __restrict__ normclip) {
+                                                    float bc2_sqrt, float gscale, const float* __restrict__ normclip,
+                                                    bf16* __restrict__ pbf) {
     const float gs = gscale * (normclip ? normclip[1] : 1.0f);
     const long long n4 = n >> 2;
     const float decay = 1.0f - lr * wd;
@@ -65,6 +66,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             pp[c] -= step * (mm[c] / denom);
         }
         reinterpret_cast<f32x4*>(p)[i] = pp;
+        if (pbf) {      // bf16 mirror of the master buffer: the forward GEMM operands are views of it
+            bf16x4 o;
+            o[0] = (bf16)pp[0]; o[1] = (bf16)pp[1]; o[2] = (bf16)pp[2]; o[3] = (bf16)pp[3];
+            reinterpret_cast<bf16x4*>(pbf)[i] = o;
+        }
         reinterpret_cast<f32x4*>(m)[i] = mm;
         reinterpret_cast<f32x4*>(v)[i] = vv;
     }
@@ -86,14 +92,15 @@ extern "C" int sc_grad_norm(const float* grads, long long n, float grad_scale, f
 
 extern "C" int sc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                             const float* norm_clip, void* stream) {
+                             const float* norm_clip, void* params_bf16, void* stream) {
     SC_CHECK(n > 0 && (n % 4) == 0 && step >= 1, "sc_adamw_step: n must be a positive multiple of 4, step >= 1");
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     long long nb = (n / 4 + 255) / 256;
     if (nb > 4096) nb = 4096;
     adamw_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                                                           weight_decay, bc1, bc2s, grad_scale, norm_clip);
+                                                           weight_decay, bc1, bc2s, grad_scale, norm_clip,
+                                                           (bf16*)params_bf16);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -278,10 +278,15 @@ def grad_norm(grads, n, grad_scale, max_norm, out2):
     return out2
 
 
-def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_scale, norm_clip):
+def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_scale, norm_clip, p_bf16=None):
     check(_lib.lib().sc_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(lr), float(beta1),
                                    float(beta2), float(eps), float(wd), int(step), float(grad_scale), _ptr(norm_clip),
-                                   _stream()), "sc_adamw_step")
+                                   _ptr(p_bf16), _stream()), "sc_adamw_step")
+
+
+def cast_transpose_batched(master, desc, tile_prefix, n, total_tiles):
+    check(_lib.lib().sc_cast_transpose_batched(master.data_ptr(), desc.data_ptr(), tile_prefix.data_ptr(), n,
+                                               total_tiles, _stream()), "sc_cast_transpose_batched")
 
 
 # ------------------------------------------------------------------------------------------ text tower glue

@@ -48,8 +48,8 @@ class FusedAdamW:
             ops.grad_norm(st.grad, st.total, grad_scale, max_norm, self.norm_clip)
             clip = self.norm_clip
         ops.adamw_step(st.master, st.grad, self.exp_avg, self.exp_avg_sq, st.total, g["lr"], g["betas"][0],
-                       g["betas"][1], g["eps"], g["weight_decay"], self.step_count, grad_scale, clip)
-        st.refresh_compute_copies()
+                       g["betas"][1], g["eps"], g["weight_decay"], self.step_count, grad_scale, clip, st.master_bf16)
+        st.refresh_compute_copies(mirror_is_fresh=True)
         return self.norm_clip
 
     def state_dict(self):

@@ -122,6 +122,9 @@ class ParamStore:
         self.total = last.offset + _round_up(max(last.numel, 1), ALIGN)
         self.master = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
+        # bf16 mirror of the master buffer (same flat layout), written by the AdamW kernel: the forward operand of
+        # every Linear whose K needs no padding is a VIEW of it, so no separate cast launch exists for those
+        self.master_bf16 = torch.zeros(self.total, dtype=torch.bfloat16, device=device)
         self.params: Dict[str, torch.nn.Parameter] = {}
         for s in self.specs:
             view = self.master[s.offset:s.offset + s.numel].view(s.shape)
@@ -189,9 +192,19 @@ class ParamStore:
     # ------------------------------------------------------------------ bf16 compute copies
     def _add_copy(self, name: str, n_out: int, k_in: int, stored_kn: bool = False, need_wb: bool = True) -> None:
         c = LinearCopy(name, n_out, k_in, stored_kn, need_wb, k_pad=_round_up(k_in, 64))
-        c.wf = torch.zeros((n_out, c.k_pad), dtype=torch.bfloat16, device=self.device)
+        sp = self.by_name[name]
+        mirror = self.master_bf16[sp.offset:sp.offset + sp.numel]
+        if not stored_kn and c.k_pad == k_in:
+            c.wf = mirror.view(n_out, k_in)                  # view of the bf16 mirror: refreshed by AdamW itself
+            c.wf_is_view = True
+        else:
+            c.wf = torch.zeros((n_out, c.k_pad), dtype=torch.bfloat16, device=self.device)
+            c.wf_is_view = False
         if need_wb:
-            c.wb = torch.zeros((k_in, n_out), dtype=torch.bfloat16, device=self.device)
+            if stored_kn:
+                c.wb = mirror.view(k_in, n_out)              # [K_in, N_out] as stored: again a view of the mirror
+            else:
+                c.wb = torch.zeros((k_in, n_out), dtype=torch.bfloat16, device=self.device)
         self.copies[name] = c
 
     def _build_copies(self) -> None:
@@ -219,17 +232,35 @@ class ParamStore:
             self._add_copy("gene.fc1.weight", g.hidden, g.n_genes, need_wb=False)
             self._add_copy("gene.fc2.weight", cfg.embed_dim, g.hidden)
 
-    def refresh_compute_copies(self) -> None:
-        """fp32 master -> bf16 GEMM operands (after init, load_state_dict and every optimiser step)."""
+    def _build_transpose_plan(self) -> None:
+        """Descriptor table of every transposed copy (wb of nn.Linear weights, wf of [K,N]-stored projections)."""
+        desc, prefix, tiles = [], [0], 0
         for c in self.copies.values():
-            src = self.p(c.name)
-            if c.stored_kn:
-                src2 = src.view(c.k_in, c.n_out)
-                ops.cast_transpose_bf16(src2, c.wf, c.k_in, c.n_out, ld_dst=c.k_pad)   # wf[n][k] = src[k][n]
-                if c.wb is not None:
-                    ops.cast_pad_bf16(src2, c.wb, c.k_in, c.n_out, c.n_out)
+            sp = self.by_name[c.name]
+            if c.stored_kn:       # wf[n][k] = src[k][n] : src is [k_in, n_out]
+                items = [(sp.offset, c.wf, c.k_in, c.n_out, c.k_pad)]
+            elif c.wb is not None:  # wb[k][n] = src[n][k] : src is [n_out, k_in]
+                items = [(sp.offset, c.wb, c.n_out, c.k_in, c.n_out)]
             else:
-                src2 = src.view(c.n_out, c.k_in)
-                ops.cast_pad_bf16(src2, c.wf, c.n_out, c.k_in, c.k_pad, ld_src=c.k_in, ld_dst=c.k_pad)
-                if c.wb is not None:
-                    ops.cast_transpose_bf16(src2, c.wb, c.n_out, c.k_in, ld_dst=c.n_out)  # wb[k][n] = src[n][k]
+                items = []
+            for off, dst, rows, cols, ldd in items:
+                desc.append([off, dst.data_ptr(), rows, cols, ldd])
+                tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+                prefix.append(tiles)
+        self._tp_n, self._tp_tiles = len(desc), tiles
+        self._tp_desc = torch.tensor(desc, dtype=torch.int64, device=self.device)
+        self._tp_prefix = torch.tensor(prefix, dtype=torch.int32, device=self.device)
+
+    def refresh_compute_copies(self, mirror_is_fresh: bool = False) -> None:
+        """fp32 master -> bf16 GEMM operands (after init, load_state_dict and every optimiser step).
+        ``mirror_is_fresh``: the AdamW kernel has just written the bf16 mirror, only padded / transposed copies remain."""
+        if not mirror_is_fresh:
+            ops.cast_pad_bf16(self.master.view(1, -1), self.master_bf16.view(1, -1), 1, self.total, self.total)
+        if getattr(self, "_tp_desc", None) is None:
+            self._build_transpose_plan()
+        if self._tp_n:
+            ops.cast_transpose_batched(self.master, self._tp_desc, self._tp_prefix, self._tp_n, self._tp_tiles)
+        for c in self.copies.values():
+            if not c.stored_kn and not c.wf_is_view:      # K-padded forward operand (gene.fc1, conv1 at patch 14)
+                ops.cast_pad_bf16(self.p(c.name).view(c.n_out, c.k_in), c.wf, c.n_out, c.k_in, c.k_pad,
+                                  ld_src=c.k_in, ld_dst=c.k_pad)

@@ -192,5 +192,7 @@ def test_adamw_and_gradnorm():
         O.adamw_step(pr, gavg, m, v, step, 1e-3)
         ops.grad_norm(gr.cuda(), n, 1.0 / W, 1.0, nc)
         assert abs(float(nc[0]) - float(norm)) < 1e-3 * float(norm)
-        ops.adamw_step(pd, gr.cuda(), md, vd, n, 1e-3, 0.9, 0.98, 1e-6, 0.1, step, 1.0 / W, nc)
+        pbf = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        ops.adamw_step(pd, gr.cuda(), md, vd, n, 1e-3, 0.9, 0.98, 1e-6, 0.1, step, 1.0 / W, nc, pbf)
         torch.testing.assert_close(pd.cpu(), pr, atol=2e-6, rtol=1e-5)
+        assert torch.equal(pbf.cpu(), pd.cpu().to(torch.bfloat16))
