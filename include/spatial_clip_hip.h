@@ -78,6 +78,10 @@ int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, long long l
                      long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum, float* ws,
                      int rows, int d, void* stream);
 
+/* u = bf16(x + bias[n]), h = bf16(gelu_erf(u)) on a dense fp32 [rows, n]: epilogue of a split-K forward Linear
+ * (gene-MLP fc1, K = 20k genes, M = batch: the K loop is split over the chip and reduced in fp32 first). */
+int sc_bias_gelu_pair(const float* x, const float* bias, void* u, void* h, int rows, int n, void* stream);
+
 /* column sums of a bf16 matrix -> fp32 (bias gradients).  ws: sc_colsum_ws_floats() floats. */
 long long sc_colsum_ws_floats(int rows, int n);
 int sc_colsum_bf16(const void* x, long long ld, int rows, int n, float* out, float* ws, void* stream);

@@ -297,6 +297,35 @@ __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const float
 
 }  // namespace
 
+// u = bf16(x + bias), h = bf16(gelu_erf(u)) : the epilogue of a split-K forward Linear (gene fc1, K = 20k)
+__global__ void bias_gelu_pair_kernel(const float* __restrict__ x, const float* __restrict__ bias, bf16* __restrict__ u,
+                                      bf16* __restrict__ h, long long total4, int n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % n);
+        const f32x4 v = ld4(x + i * 4) + ld4(bias + c);
+        bf16x4 uo, ho;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uo[k] = (bf16)v[k];
+            const float uf = (float)uo[k];
+            ho[k] = (bf16)(0.5f * uf * (1.0f + erff(uf * 0.70710678118654752f)));
+        }
+        *reinterpret_cast<bf16x4*>(u + i * 4) = uo;
+        *reinterpret_cast<bf16x4*>(h + i * 4) = ho;
+    }
+}
+
+extern "C" int sc_bias_gelu_pair(const float* x, const float* bias, void* u, void* h, int rows, int n, void* stream) {
+    SC_CHECK(rows > 0 && n > 0 && (n % 4) == 0, "sc_bias_gelu_pair: bad shape");
+    const long long total4 = (long long)rows * n / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    bias_gelu_pair_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, bias, (bf16*)u, (bf16*)h, total4, n);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sc_cast_transpose_batched(const float* master, const long long* desc, const int* tile_prefix, int n,
                                          int total_tiles, void* stream) {
     SC_CHECK(n > 0 && total_tiles > 0, "sc_cast_transpose_batched: nothing to do");

@@ -158,6 +158,12 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, cols
                              _stream()), "sc_layernorm_bwd")
 
 
+def bias_gelu_pair(x, bias, u, h, rows: int, n: int):
+    _req(x, torch.float32, "x"); _req(u, torch.bfloat16, "u"); _req(h, torch.bfloat16, "h")
+    check(_lib.lib().sc_bias_gelu_pair(x.data_ptr(), bias.data_ptr(), u.data_ptr(), h.data_ptr(), rows, n, _stream()),
+          "sc_bias_gelu_pair")
+
+
 def colsum_bf16(x, rows: int, n: int, out, ld: Optional[int] = None):
     _req(x, torch.bfloat16, "x"); _req(out, torch.float32, "out")
     l = _lib.lib()

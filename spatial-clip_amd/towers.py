@@ -417,8 +417,18 @@ class GeneTower:
         ops.cast_pad_bf16(x, xg, B, g.n_genes, self.kpad)
         u1 = bf.get("u1", (B, g.hidden), BF16)
         h1 = bf.get("h1", (B, g.hidden), BF16)
-        ops.gemm(ops.NT, ops.EPI_GELU_PAIR, xg, s.copies["gene.fc1.weight"].wf, u1, M=B, N=g.hidden, K=self.kpad,
-                 bias=s.p("gene.fc1.bias"), out2=h1)
+        # M = batch is small and K = n_genes is huge: split K over the chip (fp32 slabs), then bias + GELU
+        ktiles = self.kpad // 64
+        tiles = ((B + 127) // 128) * ((g.hidden + 127) // 128)
+        splitk = max(1, min(ktiles // 2, 256 // max(tiles, 1), 64))
+        if splitk > 1:
+            pre = bf.get("pre1", (B, g.hidden), F32)
+            ops.gemm(ops.NT, ops.EPI_F32, xg, s.copies["gene.fc1.weight"].wf, pre, M=B, N=g.hidden, K=self.kpad,
+                     splitk=splitk)
+            ops.bias_gelu_pair(pre, s.p("gene.fc1.bias"), u1, h1, B, g.hidden)
+        else:
+            ops.gemm(ops.NT, ops.EPI_GELU_PAIR, xg, s.copies["gene.fc1.weight"].wf, u1, M=B, N=g.hidden, K=self.kpad,
+                     bias=s.p("gene.fc1.bias"), out2=h1)
         f_raw = bf.get("f_raw", (B, D), F32)
         ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, h1, s.copies["gene.fc2.weight"].wf, f_raw, M=B, N=D, K=g.hidden,
                  bias=s.p("gene.fc2.bias"))
