@@ -116,32 +116,38 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) vo
                 s0 = sc_mfma16(frag_row<DH>(Kimg, k0, ks, li, lg), qf[ks], s0);
                 s1 = sc_mfma16(frag_row<DH>(Kimg, k0 + 16, ks, li, lg), qf[ks], s1);
             }
-            float mx = -1e30f;
+            // masking is needed only where the block touches the padding (last block) or the causal diagonal
+            if (k0 + 32 > L || CAUSAL) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ka = k0 + 4 * lg + r, kb = ka + 16;
-                if (ka >= L || (CAUSAL && ka > q)) s0[r] = -1e30f;
-                if (kb >= L || (CAUSAL && kb > q)) s1[r] = -1e30f;
-                mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+                for (int r = 0; r < 4; ++r) {
+                    const int ka = k0 + 4 * lg + r, kb = ka + 16;
+                    if (ka >= L || (CAUSAL && ka > q)) s0[r] = -1e30f;
+                    if (kb >= L || (CAUSAL && kb > q)) s1[r] = -1e30f;
+                }
             }
+            float mx = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])),
+                             fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
             mx = quad_max(mx);
             const float mn = fmaxf(m, mx);
-            const float alpha = exp2f((m - mn) * c2);
-            m = mn;
+            const float nb = -mn * c2;                      // exp(scale*(s - mn)) = exp2(s*c2 + nb)
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s0[r] = exp2f((s0[r] - mn) * c2);
-                s1[r] = exp2f((s1[r] - mn) * c2);
+                s0[r] = exp2f(fmaf(s0[r], c2, nb));
+                s1[r] = exp2f(fmaf(s1[r], c2, nb));
                 ps += s0[r] + s1[r];
             }
-            lsum = lsum * alpha + ps;
             const bf16x8 pf = pack8(s0, s1);
+            if (__any(mn != m)) {                           // running max moved for some query: rescale (rare after
+                const float alpha = exp2f((m - mn) * c2);   // the first blocks), otherwise alpha == 1 exactly
+                lsum *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                o[dt] *= alpha;
-                o[dt] = sc_mfma16(frag_tr<DH>(Vimg, k0, dt * 16, li, lg), pf, o[dt]);
+                for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
             }
+            m = mn;
+            lsum += ps;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt] = sc_mfma16(frag_tr<DH>(Vimg, k0, dt * 16, li, lg), pf, o[dt]);
         }
         lsum = quad_sum(lsum);
         const float inv = 1.0f / lsum;
@@ -208,11 +214,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16* __restric
                 p0 = sc_mfma16(frag_row<DH>(Vimg, k0, ks, li, lg), dof[ks], p0);
                 p1 = sc_mfma16(frag_row<DH>(Vimg, k0 + 16, ks, li, lg), dof[ks], p1);
             }
+            const bool edge = (k0 + 32 > L) || CAUSAL;      // masks only where the block touches padding / diagonal
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ka = k0 + 4 * lg + r, kb = ka + 16;
-                const float pa = (ka >= L || (CAUSAL && ka > q)) ? 0.f : exp2f(s0[r] * c2 + nl2);
-                const float pb = (kb >= L || (CAUSAL && kb > q)) ? 0.f : exp2f(s1[r] * c2 + nl2);
+                float pa = exp2f(fmaf(s0[r], c2, nl2)), pb = exp2f(fmaf(s1[r], c2, nl2));
+                if (edge) {
+                    const int ka = k0 + 4 * lg + r, kb = ka + 16;
+                    if (ka >= L || (CAUSAL && ka > q)) pa = 0.f;
+                    if (kb >= L || (CAUSAL && kb > q)) pb = 0.f;
+                }
                 s0[r] = pa * (p0[r] - dl);
                 s1[r] = pb * (p1[r] - dl);
             }
@@ -283,18 +293,24 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16* __restri
                 p1 = sc_mfma16(frag_row<DH>(Gimg, q0 + 16, ks, li, lg), vf[ks], p1);
             }
             f32x4 pr0, pr1;
+            const bool edge = (q0 + 32 > Lq) || (kt * 16 + 16 > L) || CAUSAL;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                // masked entries are forced to exact zeros (lse / delta of unused query rows may hold anything);
+                // interior blocks (no padding, no diagonal) skip the comparisons
                 const int qa = q0 + 4 * lg + r, qb = qa + 16;
-                // masked entries are forced to exact zeros (lse / delta of unused query rows may hold anything)
-                const bool ma = (qa >= Lq || key >= L || (CAUSAL && key > qa));
-                const bool mb = (qb >= Lq || key >= L || (CAUSAL && key > qb));
-                const float pa = ma ? 0.f : exp2f(s0[r] * c2 + slse[qa]);
-                const float pb = mb ? 0.f : exp2f(s1[r] * c2 + slse[qb]);
+                float pa = exp2f(fmaf(s0[r], c2, slse[qa])), pb = exp2f(fmaf(s1[r], c2, slse[qb]));
+                float da = pa * (p0[r] - sdel[qa]), db = pb * (p1[r] - sdel[qb]);
+                if (edge) {
+                    const bool ma = (qa >= Lq || key >= L || (CAUSAL && key > qa));
+                    const bool mb = (qb >= Lq || key >= L || (CAUSAL && key > qb));
+                    pa = ma ? 0.f : pa; da = ma ? 0.f : da;
+                    pb = mb ? 0.f : pb; db = mb ? 0.f : db;
+                }
                 pr0[r] = pa;
                 pr1[r] = pb;
-                s0[r] = ma ? 0.f : pa * (p0[r] - sdel[qa]);
-                s1[r] = mb ? 0.f : pb * (p1[r] - sdel[qb]);
+                s0[r] = da;
+                s1[r] = db;
             }
             const bf16x8 pf = pack8(pr0, pr1), dsf = pack8(s0, s1);
 #pragma unroll
