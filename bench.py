@@ -34,6 +34,17 @@ def flops_per_pair(cfg, G: int) -> float:
     return 3.0 * fwd
 
 
+def skipped_flops_per_pair(cfg) -> float:
+    """FLOPs of the reference formula that this build does NOT execute: in the last ViT block only the CLS token is
+    consumed downstream (pool 'tok'), so attention output, out_proj and the MLP run for 1 of the L rows."""
+    if os.environ.get("SC_CLS_ONLY", "1") == "0":
+        return 0.0
+    v = cfg.vision
+    L, d, mlp = v.tokens, v.width, int(v.width * v.mlp_ratio)
+    fwd = (L - 1) * (2.0 * d * d + 2 * (2.0 * d * mlp)) + 2 * (2.0 * (L - 1) * L * d)
+    return 3.0 * fwd
+
+
 def host_cpu_share() -> int:
     """Cores this process may really use: min(affinity, cgroup quota, SC_CPU_THREADS or 16 -- the GPU box's share)."""
     n = os.cpu_count() or 1
@@ -225,8 +236,12 @@ def main():
             roofline["wgrad_tn"] = {"achieved": round(fl2 / sec2 / 1e12, 1), "share_of_step_time": round(sec2 / dt_inst, 3),
                                     "note": "weight-gradient GEMMs (split-K slabs + fused bias-gradient column sums)"}
         step_tflops = value / world * fpp / 1e12
+        exe = fpp - skipped_flops_per_pair(cfg)
         roofline["whole_step"] = {"achieved": round(step_tflops, 1), "frac": round(step_tflops / PEAK_BF16_TFLOPS, 4),
-                                  "flops_per_pair": fpp}
+                                  "flops_per_pair": fpp, "executed_flops_per_pair": exe,
+                                  "achieved_executed": round(value / world * exe / 1e12, 1),
+                                  "note": "flops_per_pair = reference-algorithmic (SURVEY 8d); executed excludes the "
+                                          "last block's dead non-CLS token work that this build skips"}
 
     if rank == 0:
         cpu = None
