@@ -94,6 +94,29 @@ class Trainer:
             self.history.append(rec)
         self.callback_metrics = {k: v for k, v in self.history[-1].items() if isinstance(v, float)} if self.history else {}
 
+    # ------------------------------------------------------------------ checkpoints (reference state_dict names)
+    @staticmethod
+    def save_checkpoint(path: str, model, optimizer=None, scheduler=None, global_step: int = 0) -> None:
+        """``state_dict`` uses the reference ``CLIP.state_dict()`` key names, so the file loads into open_clip too."""
+        ck = {"state_dict": {k: v.cpu() for k, v in model.net.state_dict().items()}, "global_step": global_step}
+        if optimizer is not None:
+            ck["optimizer"] = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in optimizer.state_dict().items()}
+        if scheduler is not None:
+            ck["scheduler_last_epoch"] = scheduler.last_epoch
+        torch.save(ck, path)
+
+    @staticmethod
+    def load_checkpoint(path: str, model, optimizer=None, scheduler=None) -> int:
+        ck = torch.load(path, map_location="cpu")
+        model.net.load_state_dict(ck["state_dict"])
+        if optimizer is not None and "optimizer" in ck:
+            optimizer.load_state_dict({k: (v.to(model.device) if isinstance(v, torch.Tensor) else v)
+                                       for k, v in ck["optimizer"].items()})
+        if scheduler is not None and "scheduler_last_epoch" in ck:
+            scheduler.last_epoch = int(ck["scheduler_last_epoch"])
+            scheduler._apply()
+        return int(ck.get("global_step", 0))
+
     def test(self, model, datamodule, ckpt_path: Optional[str] = None):
         loader = datamodule.test_dataloader()
         n = self._limit(len(loader), 1.0)

@@ -259,3 +259,45 @@ def test_vit_l14_shapes_vs_oracle():
         g = n.store.g(k).cpu().double()
         rel = float((g - g_ref).norm() / g_ref.norm().clamp_min(1e-12))
         assert rel < 0.05, (k, rel)
+
+
+def test_checkpoint_roundtrip_resumes_identically(tmp_path):
+    """Save after 2 steps, restore into a fresh module, step both: identical loss and weights (checkpoint / resume,
+    SURVEY section 5; the state_dict carries the reference CLIP key names)."""
+    import functools
+    data, losses, mc, module, net, optim = _pkg()
+    from spatial_clip_amd.trainer import Trainer
+    cfg, _ = tiny_cfgs(64, 32, 2, 32, 8)
+
+    def make(seed):
+        n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=seed)
+        m = module.SpatialClipLitModule(
+            n, losses.ClipLoss(local_loss=True, gather_with_grad=True),
+            functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+            functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=2))
+
+        class T:
+            max_steps, max_epochs, estimated_stepping_batches = 20, None, 20
+        m.trainer = T()
+        oc = m.configure_optimizers()
+        return n, m, oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+
+    def step(m, opt, sched, s):
+        b = {k: v.cuda() for k, v in data.synthetic_batch(8, 32, cfg.gene.n_genes, K=4, step=s).items()}
+        loss = m.training_step(b, s)
+        loss.backward()
+        opt.step(grad_scale=1.0, max_norm=1.0)
+        sched.step()
+        return float(loss.detach())
+
+    n1, m1, o1, s1 = make(9)
+    for s in range(2):
+        step(m1, o1, s1, s)
+    path = str(tmp_path / "ck.pt")
+    Trainer.save_checkpoint(path, m1, o1, s1, global_step=2)
+    n2, m2, o2, s2 = make(123)                      # different init, everything comes from the file
+    assert Trainer.load_checkpoint(path, m2, o2, s2) == 2
+    la, lb = step(m1, o1, s1, 2), step(m2, o2, s2, 2)
+    assert la == lb
+    assert torch.equal(n1.store.master, n2.store.master)
+    assert set(torch.load(path)["state_dict"]) >= {"visual.conv1.weight", "visual.proj", "logit_scale"}
