@@ -80,6 +80,16 @@ SC_DEVICE bf16x8 sc_cat(bf16x4 lo, bf16x4 hi) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// compile-time loop whose body needs the index as a constant (immediate operands of inline asm)
+template <int V> struct sc_int { static constexpr int value = V; };
+template <int N, int I = 0, class F>
+SC_DEVICE void sc_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(sc_int<I>{});
+        sc_static_for<N, I + 1>(f);
+    }
+}
+
 SC_DEVICE f32x4 sc_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }

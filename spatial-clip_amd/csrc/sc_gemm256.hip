@@ -26,6 +26,32 @@ SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// ds_read_b64_tr_b16 through inline asm.  In front of the builtin form hipcc places `s_waitcnt vmcnt(0)` whenever an
+// LDS-DMA is in flight (it cannot see that the DMA fills the OTHER stage), which serialises the prefetch of K tile
+// i+1 with the fragment reads of tile i; plain ds_read_b128 (the NT path) does not get that wait.  The asm form is
+// invisible to the waitcnt pass, so the lgkmcnt waits it would have placed are written by hand (tr_wait).
+template <int OFF>
+SC_DEVICE u32x2 tr16_asm(unsigned lds_addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int CNT>
+SC_DEVICE void tr_wait(u32x2& a, u32x2& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT) : "memory");
+}
+template <int CNT>
+SC_DEVICE void tr_wait_b(u32x2 (&lo)[4], u32x2 (&hi)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                 : "n"(CNT) : "memory");
+}
+SC_DEVICE bf16x8 tr_cat(u32x2 lo, u32x2 hi) {
+    union { u32x4 u; bf16x8 b; } c;
+    c.u = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    return c.b;
+}
+
 // Issue the LDS-DMA of one K tile (A and B) : 8 wave-instructions per wave.
 template <int MODE>
 SC_DEVICE void stage_tile(const GemmArgs& g, char* sA, char* sB, int m0, int n0, int k0, int wave, int lane) {
@@ -47,6 +73,42 @@ SC_DEVICE void stage_tile(const GemmArgs& g, char* sA, char* sB, int m0, int n0,
             dma16(g.B + (size_t)(k0 + kr) * g.ldb + cb, sB + grp * 1024);
         }
     }
+}
+
+// One 32-deep K step of the TN path: 8 + 2*NI transposed reads issued back to back, the MFMAs of row-fragment i
+// start as soon as the B fragments and A fragment i have landed (LDS returns in order).
+template <int NI, int KK, bool COLSUM>
+SC_DEVICE void tn_step(unsigned sbase, const unsigned (&off_a)[NI], const unsigned (&off_b)[4], f32x4 (&acc)[NI][4],
+                       bool do_cs, int wn, float (&cs)[2]) {
+    constexpr int K0 = KK * 32 * 512, K1 = K0 + 4 * 512;
+    u32x2 bl[4], bh[4], al[NI], ah[NI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bl[j] = tr16_asm<K0>(sbase + off_b[j]);
+        bh[j] = tr16_asm<K1>(sbase + off_b[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        al[i] = tr16_asm<K0>(sbase + off_a[i]);
+        ah[i] = tr16_asm<K1>(sbase + off_a[i]);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    tr_wait_b<(2 * NI > 15 ? 15 : 2 * NI)>(bl, bh);          // lgkmcnt is a 4-bit counter
+    bf16x8 bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = tr_cat(bl[j], bh[j]);
+    sc_static_for<NI>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        tr_wait<2 * (NI - 1 - i)>(al[i], ah[i]);
+        const bf16x8 af = tr_cat(al[i], ah[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = sc_mfma16(bfr[j], af, acc[i][j]);
+        if (COLSUM && do_cs && (i >> 1) == wn) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[i & 1] += (float)af[e];
+        }
+    });
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // NI = MFMA row-fragments per wave: 8 -> the workgroup owns a full 256-row tile; 4 / 2 -> it owns one half / quarter
@@ -87,6 +149,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
     const bool do_cs = kColsum && g.colsum != nullptr && tn == 0;
     float cs[2] = {0.f, 0.f};          // each of the 4 wn-waves sums 2 of the 8 row-fragments (balanced VALU work)
 
+    // TN: byte offsets (inside a stage) of this lane's transposed-read fragments, first 4-row group of kk = 0
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    unsigned tr_off_a[NI], tr_off_b[4];
+    if (MODE == SC_GEMM_TN) {
+        const int q = li >> 2, p = li & 3;
+        const int s = q | ((lg & 1) << 2);
+        const int row = (lg * 8 + q) * 512 + p * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr_off_b[j] = TILE + row + (((wn * 4 + j) ^ s) << 5);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) tr_off_a[i] = row + ((((mw >> 4) + i) ^ s) << 5);
+    }
+
     if (nt > 0) stage_tile<MODE>(g, smem, smem + TILE, m0, n0, kbeg, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -99,10 +174,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
             char* nA = smem + (cur ^ 1) * STAGE;
             stage_tile<MODE>(g, nA, nA + TILE, m0, n0, kbeg + (it + 1) * BK, wave, lane);
         }
+        if (MODE == SC_GEMM_NT) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[NI], bfr[4];
-            if (MODE == SC_GEMM_NT) {
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[NI], bfr[4];
                 const int coff = ((kk * 4 + lg) ^ ((li >> 1) & 7)) << 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -110,35 +185,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     af[i] = *reinterpret_cast<const bf16x8*>(sA + (mw + i * 16 + li) * 128 + coff);
-            } else {
-                const int q = li >> 2, p = li & 3;
-                const int kr = kk * 32 + lg * 8 + q;
-                const int s = q | ((lg & 1) << 2);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const char* pb = sB + kr * 512 + (((wn * 4 + j) ^ s) << 5) + p * 8;
-                    bfr[j] = sc_cat(sc_lds_tr16(pb), sc_lds_tr16(pb + 4 * 512));
-                }
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const char* pa = sA + kr * 512 + ((((mw >> 4) + i) ^ s) << 5) + p * 8;
-                    af[i] = sc_cat(sc_lds_tr16(pa), sc_lds_tr16(pa + 4 * 512));
-                }
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = sc_mfma16(bfr[j], af[i], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-            if (kColsum && do_cs) {
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    if ((i >> 1) == wn) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) cs[i & 1] += (float)af[i][e];
-                    }
+                    for (int j = 0; j < 4; ++j) acc[i][j] = sc_mfma16(bfr[j], af[i], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
             }
+        } else {
+            const unsigned sbase = lds0 + cur * STAGE;
+            tn_step<NI, 0, kColsum>(sbase, tr_off_a, tr_off_b, acc, do_cs, wn, cs);
+            tn_step<NI, 1, kColsum>(sbase, tr_off_a, tr_off_b, acc, do_cs, wn, cs);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
