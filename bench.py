@@ -95,7 +95,7 @@ def pmc_traffic_nt():
         return None
     tot = n = 0
     for k, v in d.items():
-        if "gemm256_kernel<0," in k:
+        if "gemm256_kernel<0," in k or "gemm8p_kernel" in k:
             tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
             n += v["launches"]
     return round(tot / n) if n else None
@@ -224,7 +224,7 @@ def main():
         dom = "gemm_nt"
         fl, sec, cnt = agg[dom]
         ach = fl / sec / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm256_kernel<NT> (forward + dgrad GEMMs)", "achieved": round(ach, 1),
+        roofline = {"bound": "mfma", "kernel": "gemm8p_kernel (NT: forward + dgrad GEMMs)", "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": pmc_traffic_nt(), "launches_per_step": cnt // args.steps,
                     "avg_launch_us": round(sec / cnt * 1e6, 1), "flops_per_launch_avg": fl / cnt,

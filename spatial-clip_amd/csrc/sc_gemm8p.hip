@@ -1,0 +1,254 @@
+// 256x256x64 bf16 MFMA GEMM with a phase-interleaved ("ping-pong") main loop, gfx950.  NT layout only.
+//
+//   8 waves (2 x 4), each wave a 128x64 output tile (128 accumulator VGPRs) cut into four 64x32 quadrants.
+//   A K tile (64 deep) is four phases, one quadrant each: {fragment ds_reads + 2 LDS-DMA of a later half-tile ->
+//   s_barrier -> 16 MFMA -> s_barrier}.  Waves 4-7 run one barrier behind waves 0-3, and wave w shares its SIMD
+//   with wave w+4, so on every SIMD one wave is in its MFMA section while its partner reads LDS / issues DMA:
+//   the matrix pipe never waits for a fragment read, and the DMA never waits for the matrix pipe.
+//
+//   Operand tiles live in LDS as HALF-TILES of 128 rows x 64 k (16 KiB, 128-B rows, same XOR swizzle as
+//   sc_gemm256.hip): A half i holds, for each of the two M-waves, rows [64 i, 64 i + 64) of its 128 rows; B half j
+//   holds, for each of the four N-waves, columns [32 j, 32 j + 32) of its 64.  Ring = 2 K tiles x 4 half-tiles
+//   = 128 KiB.  Half-tiles are staged in the order they are consumed (A0, B0, B1, A1), six half-tiles ahead of the
+//   phase that issues them, with a counted `s_waitcnt vmcnt(8)` (four half-tiles stay in flight across the barriers).
+//
+//   Ordering rules the schedule is built on:
+//     RAW: a half-tile is read one phase after the phase whose load section waited for it (every wave waits for its
+//          own DMA, the barrier that follows publishes it to the other waves -- including the staggered group);
+//     WAR: a ring slot is restaged at the earliest two phases after the phase that read it (the staggered group
+//          retires its reads one barrier later than the leading group).
+//   Epilogues are the ones of sc_gemm256.hip (shared code in sc_gemm_common.h).
+#include "sc_gemm_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF = 128 * 64 * 2;                  // 16 KiB half-tile
+constexpr int RING = 8 * HALF;                      // 128 KiB
+constexpr int EPI_BYTES = 8 * 64 * SC_EPI_LD * 4;   // 139264
+constexpr int LDS_BYTES = EPI_BYTES > RING ? EPI_BYTES : RING;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// ring slot of half-tile q (0: A half 0, 1: B half 0, 2: B half 1, 3: A half 1) of the K tile with parity D
+constexpr int slot(int D, int q) { return D * 4 * HALF + q * HALF; }
+
+struct Stager {
+    const bf16* src[4][2];      // [q][p] : this lane's source of the two 1-KiB pieces it copies per half-tile
+    int nt;
+    int wave;
+};
+
+// One phase of K tile `t` (ring parity D):  PH = 1..4  <->  quadrant (0,0) (0,1) (1,1) (1,0).
+template <int D, int PH>
+SC_DEVICE void phase(char* smem, const Stager& S, int t, const int (&a_off)[2], const int (&b_off)[2], bf16x8 (&a)[8],
+                     bf16x8 (&b0)[4], bf16x8 (&b1)[4], f32x4 (&acc)[8][4]) {
+    // ---- load section: fragments of this quadrant that are not in registers yet ----
+    if (PH == 1) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                b0[kk * 2 + jj] = *reinterpret_cast<const bf16x8*>(smem + slot(D, 1) + b_off[kk] + jj * 2048);
+    }
+    if (PH == 2) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                b1[kk * 2 + jj] = *reinterpret_cast<const bf16x8*>(smem + slot(D, 2) + b_off[kk] + jj * 2048);
+    }
+    if (PH == 1 || PH == 3) {
+        constexpr int sl = slot(D, PH == 1 ? 0 : 3);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+                a[kk * 4 + ii] = *reinterpret_cast<const bf16x8*>(smem + sl + a_off[kk] + ii * 2048);
+    }
+    // ---- stage the half-tile six positions ahead (consumption order A0 B0 B1 A1) ----
+    constexpr int q = (PH + 1) & 3;
+    constexpr int DS = PH <= 2 ? (D ^ 1) : D;
+    const int ts = t + (PH <= 2 ? 1 : 2);
+    if (ts < S.nt) {
+        dma16(S.src[q][0] + (size_t)ts * BK, smem + slot(DS, q) + S.wave * 1024);
+        dma16(S.src[q][1] + (size_t)ts * BK, smem + slot(DS, q) + (8 + S.wave) * 1024);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // retires the half-tile read in the NEXT phase
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ring is draining: fewer than four in flight
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- MFMA section ----
+    constexpr int mi = PH >= 3 ? 1 : 0;
+    constexpr int nj = (PH == 2 || PH == 3) ? 1 : 0;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                acc[mi * 4 + ii][nj * 2 + jj] =
+                    sc_mfma16(nj ? b1[kk * 2 + jj] : b0[kk * 2 + jj], a[kk * 4 + ii], acc[mi * 4 + ii][nj * 2 + jj]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int D>
+SC_DEVICE void ktile(char* smem, const Stager& S, int t, const int (&a_off)[2], const int (&b_off)[2], bf16x8 (&a)[8],
+                     bf16x8 (&b0)[4], bf16x8 (&b1)[4], f32x4 (&acc)[8][4]) {
+    phase<D, 1>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+    phase<D, 2>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+    phase<D, 3>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+    phase<D, 4>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+
+    int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = idx % g.ntn;
+    idx /= g.ntn;
+    const int tm = idx % g.ntm;
+    const int z = idx / g.ntm;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    Stager S;
+    S.nt = (kend - kbeg) / BK;
+    S.wave = wave;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = (p * 8 + wave) * 8 + (lane >> 3);          // row of the half-tile image, 128 B per row
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);              // logical 16-byte chunk stored at physical lane&7
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ga = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), g.M - 1);
+            const int gb = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), g.N - 1);
+            S.src[h ? 3 : 0][p] = g.A + (size_t)ga * g.lda + kbeg + lc * 8;
+            S.src[h ? 2 : 1][p] = g.B + (size_t)gb * g.ldb + kbeg + lc * 8;
+        }
+    }
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int coff = ((kk * 4 + lg) ^ ((li >> 1) & 7)) << 4;
+        a_off[kk] = (wr * 64 + li) * 128 + coff;
+        b_off[kk] = (wc * 32 + li) * 128 + coff;
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: the first six half-tiles (all of K tile 0, A0 and B0 of K tile 1)
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int ts = s >> 2, q = s & 3;
+        if (ts < S.nt) {
+            dma16(S.src[q][0] + (size_t)ts * BK, smem + slot(ts & 1, q) + wave * 1024);
+            dma16(S.src[q][1] + (size_t)ts * BK, smem + slot(ts & 1, q) + (8 + wave) * 1024);
+        }
+    }
+    if (S.nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                   // waves 4-7 run one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8 a[8], b0[4], b1[4];
+    for (int kt = 0; kt < S.nt; kt += 2) {
+        ktile<0>(smem, S, kt, a_off, b_off, a, b0, b1, acc);
+        if (kt + 1 < S.nt) ktile<1>(smem, S, kt + 1, a_off, b_off, a, b0, b1, acc);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();                   // re-align the two wave groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------- epilogue: two 64-row halves of the wave's 128x64 tile through a private LDS region ----------------
+    const int mw = wr * 128;
+    float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
+    EpiRegs<EPI> er;
+    sc_epi_load<EPI>(er, m0 + mw, n0 + wc * 64, lane, g, 64);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc_epi_put(ep, i, j, li, lg, acc[h * 4 + i][j]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        sc_epilogue_store<EPI>(ep, er, m0 + mw + h * 64, n0 + wc * 64, lane, g, z, (h + 1 < 2) ? m0 + mw + 64 : -1, 64);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int EPI>
+int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    gemm8p_kernel<EPI><<<nblocks, 512, LDS_BYTES, st>>>(g);
+    SC_LAUNCH_CHECK();
+    return 1;
+}
+
+}  // namespace
+
+int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st) {
+    if (mode != SC_GEMM_NT) return 0;
+    if (g.M < 256 || g.N < 192 || (g.K % BK) != 0) return 0;
+    if ((long long)g.M * g.N < 256LL * 256 * 8) return 0;
+    g.ntm = (g.M + BM - 1) / BM;
+    g.ntn = (g.N + BN - 1) / BN;
+    const int ktiles = g.K / BK;
+    int splitk = splitk_req < 1 ? 1 : splitk_req;
+    if (epi != SC_EPI_F32 || slabs == nullptr) splitk = 1;
+    if (splitk > ktiles) splitk = ktiles;
+    int tiles_per = (ktiles + splitk - 1) / splitk;
+    splitk = (ktiles + tiles_per - 1) / tiles_per;
+    g.splitk = splitk;
+    g.k_per_split = tiles_per * BK;
+    g.slab_stride = 0;
+    if (splitk > 1) {
+        if (g.ldc != g.N) return 0;
+        g.C = slabs;
+        g.slab_stride = (long long)g.M * g.N;
+    }
+    const int nblocks = g.ntm * g.ntn * splitk;
+    int rc = 0;
+#define SC_CASE(EPI) \
+    if (epi == EPI) rc = launch<EPI>(g, nblocks, st);
+    SC_CASE(SC_EPI_BF16)
+    SC_CASE(SC_EPI_BF16_BIAS)
+    SC_CASE(SC_EPI_F32_BIAS_RES)
+    SC_CASE(SC_EPI_GELU_PAIR)
+    SC_CASE(SC_EPI_BF16_DGELU)
+    SC_CASE(SC_EPI_F32)
+#undef SC_CASE
+    return rc;
+}

@@ -173,3 +173,5 @@ int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs,
 int sc_gemm_p3_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
 // 256x256x32 4-stage ring variant (sc_gemm_s4.hip): same contract
 int sc_gemm_s4_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
+// 256x256x64 phase-interleaved (ping-pong) kernel, NT only (sc_gemm8p.hip)
+int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);

@@ -50,6 +50,36 @@ def test_nt_asymmetric_identity():
     assert torch.equal(o32.cpu(), a.float() @ b.float().t())
 
 
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 448, 576, 1024])
+def test_nt_phase_interleaved_ring_exact(K):
+    """The 256x256 phase-interleaved kernel keeps six half-tiles in flight in an 8-slot LDS ring; small-integer
+    operands make every fp32 sum exact, so a fragment read from a stale or half-landed ring slot cannot hide in a
+    tolerance.  K sweeps 1..16 K tiles (prologue-only, odd/even tile counts, ring wrap), M/N ragged, repeated with
+    fresh data so an intermittent ordering bug has many chances to show."""
+    ops = _ops()
+    M, N = 256 * 3 + 40, 256 * 2 + 24
+    g = torch.Generator().manual_seed(K)
+    for rep in range(6):
+        a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+        b = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
+        ref = a.float() @ b.float().t()
+        o32 = torch.full((M, N), 5.0, dtype=torch.float32, device="cuda")
+        ops.gemm(ops.NT, ops.EPI_F32, a.cuda(), b.cuda(), o32, M=M, N=N, K=K)
+        assert torch.equal(o32.cpu(), ref), (K, rep)
+
+
+def test_nt_phase_interleaved_splitk_exact():
+    ops = _ops()
+    M, N, K = 512, 512, 64 * 13
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+    b = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
+    for splitk in (1, 2, 4, 13):
+        o32 = torch.full((M, N), 5.0, dtype=torch.float32, device="cuda")
+        ops.gemm(ops.NT, ops.EPI_F32, a.cuda(), b.cuda(), o32, M=M, N=N, K=K, splitk=splitk)
+        assert torch.equal(o32.cpu(), a.float() @ b.float().t()), splitk
+
+
 @pytest.mark.parametrize("M,N,K", [(333, 192, 256), (197 * 4, 768, 192), (700, 264, 64)])
 def test_nt_residual_gelu_dgelu(M, N, K):
     ops = _ops()
