@@ -321,7 +321,11 @@ extern "C" int sc_gemm_wgrad_bias(const void* dY, int lddy, const void* X, int l
     g.aux = nullptr; g.ldaux = 0; g.tile_offset = 0;
     g.colsum = cs_part;
     int took = 0;
-    if (!force || force[0] == '2') took = sc_gemm256_try(SC_GEMM_TN, SC_EPI_F32, g, splitk, slab_floats ? slabs : nullptr, dW, st);
+    if (!force) took = sc_gemm8p_try(SC_GEMM_TN, SC_EPI_F32, g, splitk, slab_floats ? slabs : nullptr, st);
+    if (took == 0 && (!force || force[0] == '2')) {
+        g.C = dW;
+        took = sc_gemm256_try(SC_GEMM_TN, SC_EPI_F32, g, splitk, slab_floats ? slabs : nullptr, dW, st);
+    }
     if (took < 0) return took;
     if (took == 1) {
         const long long n4 = (long long)M * N / 4;

@@ -217,11 +217,234 @@ int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
     return 1;
 }
 
+
+// =====================================================================================================================
+// TN layout (weight gradients): C[m,n] = sum_k At[k,m] Bt[k,n], both operands k-major in global memory.
+//   Half-tile image = [64 k][128 columns] bf16 (256-B rows); A half i = tile columns [128 i, 128 i + 128), of which
+//   M-wave wr owns [64 wr, 64 wr + 64); B half j likewise with N-wave wc owning [32 wc, 32 wc + 32) -- so a wave's
+//   128x64 output is rows {128 i + 64 wr + ..} x columns {128 j + 32 wc + ..} (2 x 2 blocks of 64 x 32), and every
+//   DMA row is one contiguous 256-B run of the source.  Fragments come out of LDS through ds_read_b64_tr_b16 (inline
+//   asm + hand-placed lgkmcnt: see sc_gemm256.hip), 32-B chunk ^= (k & 3) | ((k >> 3) & 1) << 2 keeps the 8 rows a
+//   32-lane half touches on distinct banks.  Phase / ring schedule identical to the NT kernel above.
+template <int OFF>
+SC_DEVICE u32x2 tr16_asm(unsigned lds_addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF) : "memory");
+    return r;
+}
+SC_DEVICE bf16x8 tr_cat(u32x2 lo, u32x2 hi) {
+    union { u32x4 u; bf16x8 b; } c;
+    c.u = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    return c.b;
+}
+
+struct FragTN {                 // one operand fragment set: [kk][f] as two 64-bit halves
+    u32x2 lo, hi;
+};
+
+template <int NF>
+SC_DEVICE void tn_read(unsigned base, const unsigned (&off)[NF], FragTN (&f)[2 * NF]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int x = 0; x < NF; ++x) {
+            if (kk == 0) {
+                f[x].lo = tr16_asm<0>(base + off[x]);
+                f[x].hi = tr16_asm<1024>(base + off[x]);
+            } else {
+                f[NF + x].lo = tr16_asm<8192>(base + off[x]);
+                f[NF + x].hi = tr16_asm<8192 + 1024>(base + off[x]);
+            }
+        }
+}
+
+struct StagerTN {
+    const bf16* src[4][2];
+    long long step[4];          // elements per K tile (64 source rows) for each half-tile kind
+    int nt;
+    int wave;
+};
+
+template <int D, int PH>
+SC_DEVICE void phase_tn(char* smem, unsigned lds0, const StagerTN& S, int t, const unsigned (&a_off)[4],
+                        const unsigned (&b_off)[2], FragTN (&a)[8], FragTN (&b0)[4], FragTN (&b1)[4], f32x4 (&acc)[8][4],
+                        bool do_cs, int wc, float (&cs)[2]) {
+    if (PH == 1) tn_read<2>(lds0 + slot(D, 1), b_off, b0);
+    if (PH == 2) tn_read<2>(lds0 + slot(D, 2), b_off, b1);
+    if (PH == 1) tn_read<4>(lds0 + slot(D, 0), a_off, a);
+    if (PH == 3) tn_read<4>(lds0 + slot(D, 3), a_off, a);
+    constexpr int q = (PH + 1) & 3;
+    constexpr int DS = PH <= 2 ? (D ^ 1) : D;
+    const int ts = t + (PH <= 2 ? 1 : 2);
+    if (ts < S.nt) {
+        dma16(S.src[q][0] + ts * S.step[q], smem + slot(DS, q) + S.wave * 1024);
+        dma16(S.src[q][1] + ts * S.step[q], smem + slot(DS, q) + (8 + S.wave) * 1024);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int mi = PH >= 3 ? 1 : 0;
+    constexpr int nj = (PH == 2 || PH == 3) ? 1 : 0;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const bf16x8 af = tr_cat(a[kk * 4 + ii].lo, a[kk * 4 + ii].hi);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const FragTN& bf = nj ? b1[kk * 2 + jj] : b0[kk * 2 + jj];
+                acc[mi * 4 + ii][nj * 2 + jj] = sc_mfma16(tr_cat(bf.lo, bf.hi), af, acc[mi * 4 + ii][nj * 2 + jj]);
+            }
+            // fused bias gradient: column sums of At over this K tile, one 16-column fragment per wave (ii == wc),
+            // taken from the A fragments when they are first used (PH 1: half 0, PH 3: half 1); the VALU adds sit
+            // between the MFMAs so they issue in the matrix pipe's shadow
+            if ((PH == 1 || PH == 3) && do_cs && ii == wc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[mi] += (float)af[e];
+            }
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int D>
+SC_DEVICE void ktile_tn(char* smem, unsigned lds0, const StagerTN& S, int t, const unsigned (&a_off)[4],
+                        const unsigned (&b_off)[2], FragTN (&a)[8], FragTN (&b0)[4], FragTN (&b1)[4], f32x4 (&acc)[8][4],
+                        bool do_cs, int wc, float (&cs)[2]) {
+    phase_tn<D, 1>(smem, lds0, S, t, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+    phase_tn<D, 2>(smem, lds0, S, t, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+    phase_tn<D, 3>(smem, lds0, S, t, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+    phase_tn<D, 4>(smem, lds0, S, t, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm8p_tn_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+
+    int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = idx % g.ntn;
+    idx /= g.ntn;
+    const int tm = idx % g.ntm;
+    const int z = idx / g.ntm;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    StagerTN S;
+    S.nt = (kend - kbeg) / BK;
+    S.wave = wave;
+    S.step[0] = S.step[3] = (long long)BK * g.lda;
+    S.step[1] = S.step[2] = (long long)BK * g.ldb;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int kr = p * 32 + wave * 4 + (lane >> 4);                 // k row of the half-tile image, 256 B per row
+        const int s = (kr & 3) | (((kr >> 3) & 1) << 2);
+        const int c = ((((lane & 15) >> 1) ^ s) << 4) + (lane & 1) * 8;  // logical column held at physical lane&15
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ca = min(m0 + h * 128 + c, g.M - 8), cb = min(n0 + h * 128 + c, g.N - 8);
+            S.src[h ? 3 : 0][p] = g.A + (size_t)(kbeg + kr) * g.lda + ca;
+            S.src[h ? 2 : 1][p] = g.B + (size_t)(kbeg + kr) * g.ldb + cb;
+        }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    unsigned a_off[4], b_off[2];
+    {
+        const int q = li >> 2, p = li & 3;
+        const int s = q | ((lg & 1) << 2);
+        const int row = (lg * 8 + q) * 256 + p * 8;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) a_off[ii] = row + (((wr * 4 + ii) ^ s) << 5);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) b_off[jj] = row + (((wc * 2 + jj) ^ s) << 5);
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = g.colsum != nullptr && tn == 0;
+    float cs[2] = {0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int ts = s >> 2, q = s & 3;
+        if (ts < S.nt) {
+            dma16(S.src[q][0] + ts * S.step[q], smem + slot(ts & 1, q) + wave * 1024);
+            dma16(S.src[q][1] + ts * S.step[q], smem + slot(ts & 1, q) + (8 + wave) * 1024);
+        }
+    }
+    if (S.nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    FragTN a[8], b0[4], b1[4];
+    for (int kt = 0; kt < S.nt; kt += 2) {
+        ktile_tn<0>(smem, lds0, S, kt, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+        if (kt + 1 < S.nt) ktile_tn<1>(smem, lds0, S, kt + 1, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (do_cs) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v = cs[h];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int m = m0 + h * 128 + wr * 64 + wc * 16 + li;
+            if (lg == 0 && m < g.M) g.colsum[(size_t)z * g.M + m] = v;
+        }
+    }
+    float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
+    EpiRegs<SC_EPI_F32> er;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc_epi_put(ep, i, j, li, lg, acc[h * 4 + i][j]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        sc_epilogue_store<SC_EPI_F32>(ep, er, m0 + h * 128 + wr * 64, n0 + wc * 32, lane, g, z, -1, 64, 128 - 32);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_tn(const GemmArgs& g, int nblocks, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_tn_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    gemm8p_tn_kernel<<<nblocks, 512, LDS_BYTES, st>>>(g);
+    SC_LAUNCH_CHECK();
+    return 1;
+}
+
 }  // namespace
 
 int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st) {
-    if (mode != SC_GEMM_NT) return 0;
     if (g.M < 256 || g.N < 192 || (g.K % BK) != 0) return 0;
+    if (mode == SC_GEMM_TN && (epi != SC_EPI_F32 || (g.M % 8) != 0 || (g.N % 8) != 0)) return 0;
     if ((long long)g.M * g.N < 256LL * 256 * 8) return 0;
     g.ntm = (g.M + BM - 1) / BM;
     g.ntn = (g.N + BN - 1) / BN;
@@ -240,6 +463,7 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
         g.slab_stride = (long long)g.M * g.N;
     }
     const int nblocks = g.ntm * g.ntn * splitk;
+    if (mode == SC_GEMM_TN) return launch_tn(g, nblocks, st);
     int rc = 0;
 #define SC_CASE(EPI) \
     if (epi == EPI) rc = launch<EPI>(g, nblocks, st);

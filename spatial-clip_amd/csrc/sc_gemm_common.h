@@ -94,14 +94,15 @@ SC_DEVICE void sc_epi_load(EpiRegs<EPI>& e, int gm0, int gn0, int lane, const Ge
 
 // Drain a wave-private 64x64 fp32 tile (row stride SC_EPI_LD) to global memory with full-row-segment accesses.
 // If next_gm0 >= 0 the input registers are refilled for the sub-tile at (next_gm0, gn0) as they are consumed.
+// hi_col_skip: the tile's columns 32..63 sit that many columns further right in C (two 32-column blocks; fp32 only).
 template <int EPI>
 SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int gn0, int lane, const GemmArgs& g, int z,
-                                 int next_gm0 = -1, int mrows = 64) {
+                                 int next_gm0 = -1, int mrows = 64, int hi_col_skip = 0) {
     const int mlim = min(g.M, gm0 + mrows);
     if (EPI == SC_EPI_F32 || EPI == SC_EPI_F32_BIAS_RES) {
         float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.slab_stride;
         const int col = (lane & 15) * 4;
-        const int gn = gn0 + col;
+        const int gn = gn0 + col + ((col >> 5) ? hi_col_skip : 0);
         f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (EPI == SC_EPI_F32_BIAS_RES && g.bias && gn < g.N) bv = *reinterpret_cast<const f32x4*>(g.bias + gn);
 #pragma unroll

@@ -119,6 +119,25 @@ def test_tn_wgrad(M, N, K, splitk):
     torch.testing.assert_close(o32.cpu(), ref, atol=2e-3 * max(1, K ** 0.5 / 8), rtol=2e-3)
 
 
+@pytest.mark.parametrize("K,splitk", [(64, 1), (128, 1), (192, 1), (320, 1), (576, 1), (1024, 1), (64 * 13, 4), (64 * 9, 9)])
+def test_tn_phase_interleaved_ring_exact(K, splitk):
+    """TN twin of the ring test above (transposed LDS reads, fused bias-gradient column sums): exact on small integers."""
+    ops = _ops()
+    M, N = 256 * 2 + 40, 256 * 3 + 24
+    g = torch.Generator().manual_seed(K + splitk)
+    for rep in range(4):
+        dy = torch.randint(-3, 4, (K, M), generator=g).to(torch.bfloat16)
+        x = torch.randint(-3, 4, (K, N), generator=g).to(torch.bfloat16)
+        dw = torch.full((M, N), 9.0, dtype=torch.float32, device="cuda")
+        db = torch.full((M,), 9.0, dtype=torch.float32, device="cuda")
+        ops.gemm_wgrad_bias(dy.cuda(), x.cuda(), dw, db, M=M, N=N, K=K, splitk=splitk)
+        assert torch.equal(dw.cpu(), dy.float().t() @ x.float()), (K, splitk, rep)
+        assert torch.equal(db.cpu(), dy.float().sum(0)), (K, splitk, rep)
+        o32 = torch.full((M, N), -3.0, dtype=torch.float32, device="cuda")
+        ops.gemm(ops.TN, ops.EPI_F32, dy.cuda(), x.cuda(), o32, M=M, N=N, K=K, splitk=splitk)
+        assert torch.equal(o32.cpu(), dy.float().t() @ x.float())
+
+
 def test_tn_asymmetric_exact():
     ops = _ops()
     K, M, N = 64, 128, 128
