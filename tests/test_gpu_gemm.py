@@ -68,6 +68,26 @@ def test_nt_phase_interleaved_ring_exact(K):
         assert torch.equal(o32.cpu(), ref), (K, rep)
 
 
+@pytest.mark.parametrize("K", [192, 256, 448])
+def test_nt_persistent_tile_walk_exact(K):
+    """More than 256 tiles + a store-only bf16 epilogue selects the persistent kernel (one workgroup per CU walks a
+    tile list, the DMA ring runs across tile boundaries).  Exact on small integers; M is ragged so both the counted
+    (interior tile) and the draining (edge tile) post-epilogue waits are exercised; several rounds of tiles."""
+    ops = _ops()
+    M, N = 256 * 64 + 72, 256 * 16
+    g = torch.Generator().manual_seed(K)
+    for rep in range(3):
+        a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+        b = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
+        bias = torch.randint(-4, 5, (N,), generator=g).float()
+        ref = a.cuda().float() @ b.cuda().float().t()
+        out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(ops.NT, ops.EPI_BF16, a.cuda(), b.cuda(), out, M=M, N=N, K=K)
+        assert torch.equal(out, ref.to(torch.bfloat16)), (K, rep)
+        ops.gemm(ops.NT, ops.EPI_BF16_BIAS, a.cuda(), b.cuda(), out, M=M, N=N, K=K, bias=bias.cuda())
+        assert torch.equal(out, (ref + bias.cuda()).to(torch.bfloat16)), (K, rep, "bias")
+
+
 def test_nt_phase_interleaved_splitk_exact():
     ops = _ops()
     M, N, K = 512, 512, 64 * 13

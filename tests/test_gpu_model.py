@@ -301,3 +301,27 @@ def test_checkpoint_roundtrip_resumes_identically(tmp_path):
     assert la == lb
     assert torch.equal(n1.store.master, n2.store.master)
     assert set(torch.load(path)["state_dict"]) >= {"visual.conv1.weight", "visual.proj", "logit_scale"}
+
+
+def test_side_stream_weight_gradients_are_bit_identical(monkeypatch):
+    """Weight-gradient GEMMs run on a side HIP stream by default (SC_OVERLAP=1); buffer rotation + events must make
+    that invisible: gradients after a backward pass are bit-identical to the single-stream schedule."""
+    data, losses, mc, module, net, optim = _pkg()
+    cfg, _ = tiny_cfgs(128, 64, 3, 48, 16)
+    B = 24
+    batch = data.synthetic_batch(B, 48, cfg.gene.n_genes, K=4, step=0)
+    grads = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("SC_OVERLAP", mode)
+        n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=3)
+        perturb(n)
+        loss_fn = losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True)
+        m = module.SpatialClipLitModule(n, loss_fn, None, None)
+        out = m.model_step({k: v.cuda() for k, v in batch.items()})
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        g = {k: n.store.g(k).clone() for k in n.state_dict()}
+        for other in grads.values():
+            for k in g:
+                assert torch.equal(g[k], other[k]), (mode, k)
+        grads[mode + str(len(grads))] = g
