@@ -11,7 +11,8 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
 from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspatialclip_hip.so")
+# SC_HIP_LIB points at an alternative build of the same ABI (A/B benchmarking of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("SC_HIP_LIB") or os.path.join(_HERE, "lib", "libspatialclip_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "spatial_clip_hip.h")
 _lib = None
 

@@ -32,15 +32,36 @@ struct Img {
     static SC_DEVICE int off(int row, int chunk16) { return row * ROWB + ((chunk16 ^ swz(row)) << 4); }
 };
 
-// cooperative load of rows [0,L) x DH of one head into an LDS image, zero-filling rows [L, Lp)
+// cooperative load of rows [0,L) x DH of one head into TWO LDS images (K and V, or Q and dO), zero-filling rows
+// [L, Lp).  All the 16-byte loads of a batch (4 per image and thread) are issued before the first LDS store, so a
+// workgroup pays ONE global-memory round trip for both images instead of one per loop trip.
 template <int DH>
-SC_DEVICE void load_image(char* img, const bf16* src, long long row_stride, int L, int Lp, int t) {
-    constexpr int CH = DH / 8;
-    for (int c = t; c < Lp * CH; c += blockDim.x) {
-        const int row = c / CH, ch = c % CH;
-        u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-        if (row < L) v = *reinterpret_cast<const u32x4*>(src + (long long)row * row_stride + ch * 8);
-        *reinterpret_cast<u32x4*>(img + Img<DH>::off(row, ch)) = v;
+SC_DEVICE void load_images2(char* img_a, const bf16* src_a, long long stride_a, char* img_b, const bf16* src_b,
+                            long long stride_b, int L, int Lp, int t) {
+    constexpr int CH = DH / 8, NB = 4;
+    const int total = Lp * CH, step = blockDim.x;
+    for (int c0 = t; c0 < total; c0 += NB * step) {
+        u32x4 va[NB], vb[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u * step;
+            const int row = c / CH, ch = c % CH;
+            va[u] = (u32x4){0u, 0u, 0u, 0u};
+            vb[u] = (u32x4){0u, 0u, 0u, 0u};
+            if (c < total && row < L) {
+                va[u] = *reinterpret_cast<const u32x4*>(src_a + (long long)row * stride_a + ch * 8);
+                vb[u] = *reinterpret_cast<const u32x4*>(src_b + (long long)row * stride_b + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u * step;
+            if (c < total) {
+                const int row = c / CH, ch = c % CH;
+                *reinterpret_cast<u32x4*>(img_a + Img<DH>::off(row, ch)) = va[u];
+                *reinterpret_cast<u32x4*>(img_b + Img<DH>::off(row, ch)) = vb[u];
+            }
+        }
     }
 }
 
@@ -69,14 +90,32 @@ SC_DEVICE bf16x8 pack8(f32x4 a, f32x4 b) {
     return r;
 }
 
+// exchange with the lane 16 / 32 positions away without LDS: v_permlane{16,32}_swap on (v, v) leaves the partner's
+// value in one of the two results in every lane -> xor-16 / xor-32 butterflies in one VALU instruction each
+SC_DEVICE float xor16(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    // r[0]: odd 16-lane rows hold the even neighbour's value; r[1]: even rows hold the odd neighbour's value
+    const bool odd = (threadIdx.x & 16) != 0;
+    return __builtin_bit_cast(float, odd ? r[0] : r[1]);
+}
+SC_DEVICE float xor32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const bool hi = (threadIdx.x & 32) != 0;
+    return __builtin_bit_cast(float, hi ? r[0] : r[1]);
+}
 SC_DEVICE float quad_max(float v) {  // over the 4 lanes that share lane&15
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+    v = fmaxf(v, xor16(v));
+    return fmaxf(v, xor32(v));
 }
 SC_DEVICE float quad_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    v += xor16(v);
+    return v + xor32(v);
 }
+// raw v_exp_f32 (2^x): arguments here are <= 0 or moderately positive; results below the normal range flush to 0,
+// which is what a masked / far-below-max probability should be (exp2f() adds 5 range-fixup instructions per call)
+SC_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ---------------------------------------------------------------------------------------------- forward
 template <int DH, bool CAUSAL>
@@ -92,18 +131,30 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) vo
     const int Lp = (L + 31) & ~31;
     char* Kimg = smem;
     char* Vimg = smem + Lp * DH * 2;
-    load_image<DH>(Kimg, base + d, rs, L, Lp, t);
-    load_image<DH>(Vimg, base + 2 * d, rs, L, Lp, t);
+    // the first query tile's fragments travel together with the K/V images (one memory round trip, not two)
+    bf16x8 qnext[KS];
+    {
+        const int qc0 = min(wave * 16 + li, L - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            qnext[ks] = *reinterpret_cast<const bf16x8*>(base + (long long)qc0 * rs + ks * 32 + lg * 8);
+    }
+    load_images2<DH>(Kimg, base + d, rs, Vimg, base + 2 * d, rs, L, Lp, t);
     __syncthreads();
     const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
     const int nqt = (Lq + 15) >> 4;        // only the first Lq query rows are needed
-    for (int qt = wave; qt < nqt; qt += (blockDim.x >> 6)) {
+    const int nwaves = blockDim.x >> 6;
+    for (int qt = wave; qt < nqt; qt += nwaves) {
         const int q = qt * 16 + li;           // this lane's query (B-operand column)
-        const int qc = min(q, L - 1);
         bf16x8 qf[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long long)qc * rs + ks * 32 + lg * 8);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = qnext[ks];
+        if (qt + nwaves < nqt) {              // prefetch the next tile of this wave (L > 16 * waves only)
+            const int qc1 = min((qt + nwaves) * 16 + li, L - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qnext[ks] = *reinterpret_cast<const bf16x8*>(base + (long long)qc1 * rs + ks * 32 + lg * 8);
+        }
         f32x4 o[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -133,13 +184,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) vo
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s0[r] = exp2f(fmaf(s0[r], c2, nb));
-                s1[r] = exp2f(fmaf(s1[r], c2, nb));
+                s0[r] = fast_exp2(fmaf(s0[r], c2, nb));
+                s1[r] = fast_exp2(fmaf(s1[r], c2, nb));
                 ps += s0[r] + s1[r];
             }
             const bf16x8 pf = pack8(s0, s1);
             if (__any(mn != m)) {                           // running max moved for some query: rescale (rare after
-                const float alpha = exp2f((m - mn) * c2);   // the first blocks), otherwise alpha == 1 exactly
+                const float alpha = fast_exp2((m - mn) * c2);   // the first blocks), otherwise alpha == 1 exactly
                 lsum *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
@@ -178,8 +229,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16* __restric
     const int Lp = (L + 31) & ~31;
     char* Kimg = smem;
     char* Vimg = smem + Lp * DH * 2;
-    load_image<DH>(Kimg, base + d, rs, L, Lp, t);
-    load_image<DH>(Vimg, base + 2 * d, rs, L, Lp, t);
+    load_images2<DH>(Kimg, base + d, rs, Vimg, base + 2 * d, rs, L, Lp, t);
     __syncthreads();
     const float c2 = scale * 1.4426950408889634f;
     const int nqt = (Lq + 15) >> 4;        // only the first Lq query rows are needed
@@ -217,7 +267,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dq_kernel(const bf16* __restric
             const bool edge = (k0 + 32 > L) || CAUSAL;      // masks only where the block touches padding / diagonal
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float pa = exp2f(fmaf(s0[r], c2, nl2)), pb = exp2f(fmaf(s1[r], c2, nl2));
+                float pa = fast_exp2(fmaf(s0[r], c2, nl2)), pb = fast_exp2(fmaf(s1[r], c2, nl2));
                 if (edge) {
                     const int ka = k0 + 4 * lg + r, kb = ka + 16;
                     if (ka >= L || (CAUSAL && ka > q)) pa = 0.f;
@@ -260,8 +310,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16* __restri
     char* Gimg = smem + Lp * DH * 2;
     float* slse = reinterpret_cast<float*>(smem + 2 * Lp * DH * 2);
     float* sdel = slse + Lp;
-    load_image<DH>(Qimg, base, rs, L, Lp, t);
-    load_image<DH>(Gimg, dout + (long long)b * L * d + h * DH, d, L, Lp, t);
+    load_images2<DH>(Qimg, base, rs, Gimg, dout + (long long)b * L * d + h * DH, d, L, Lp, t);
     for (int i = t; i < Lp; i += blockDim.x) {
         slse[i] = i < L ? -lse[((long long)b * H + h) * L + i] * 1.4426950408889634f : 0.f;
         sdel[i] = i < L ? delta[((long long)b * H + h) * L + i] : 0.f;
@@ -299,7 +348,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16* __restri
                 // masked entries are forced to exact zeros (lse / delta of unused query rows may hold anything);
                 // interior blocks (no padding, no diagonal) skip the comparisons
                 const int qa = q0 + 4 * lg + r, qb = qa + 16;
-                float pa = exp2f(fmaf(s0[r], c2, slse[qa])), pb = exp2f(fmaf(s1[r], c2, slse[qb]));
+                float pa = fast_exp2(fmaf(s0[r], c2, slse[qa])), pb = fast_exp2(fmaf(s1[r], c2, slse[qb]));
                 float da = pa * (p0[r] - sdel[qa]), db = pb * (p1[r] - sdel[qb]);
                 if (edge) {
                     const bool ma = (qa >= Lq || key >= L || (CAUSAL && key > qa));

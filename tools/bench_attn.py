@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Attention forward / backward alone on the ViT-B/16 shape (B=256, L=197, H=12, dh=64)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import spatial_clip_amd  # noqa
+from spatial_clip_amd import ops
+
+B, L, H, dh = int(os.environ.get("B", 256)), 197, 12, 64
+d = H * dh
+g = torch.Generator(device="cuda").manual_seed(0)
+qkv = torch.randn(B * L, 3 * d, device="cuda", generator=g).bfloat16()
+out = torch.empty(B * L, d, device="cuda", dtype=torch.bfloat16)
+lse = torch.empty(B, H, L, device="cuda")
+dout = torch.randn(B * L, d, device="cuda", generator=g).bfloat16()
+dqkv = torch.empty_like(qkv)
+delta = torch.empty(B, H, L, device="cuda")
+n = int(os.environ.get("N", 20))
+
+
+def timeit(fn, name, bytes_):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    print(f"{name:10s} {us:8.1f} us   {bytes_ / us / 1e6:6.2f} TB/s algorithmic", flush=True)
+
+
+qb = qkv.numel() * 2
+ob = out.numel() * 2
+timeit(lambda: ops.attn_fwd(qkv, B, L, H, dh, False, out=out, lse=lse), "fwd", qb + ob)
+timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, dh, False, dqkv=dqkv, delta=delta), "bwd", 2 * qb + 3 * ob + qb)
