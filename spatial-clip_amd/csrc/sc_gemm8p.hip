@@ -17,8 +17,8 @@
 //          own DMA, the barrier that follows publishes it to the other waves -- including the staggered group);
 //     WAR: a ring slot is restaged at the earliest two phases after the phase that read it (the staggered group
 //          retires its reads one barrier later than the leading group).
-//   Epilogue: store-only bf16 outputs go straight from the accumulator registers to global memory
-//   (epilogue_direct); the others take the LDS-staged path shared with sc_gemm256.hip (sc_gemm_common.h).
+//   Epilogue: bf16 outputs without an extra input tile take a bf16 LDS strip (epilogue_bf16_lds); the others the
+//   fp32 LDS staging shared with sc_gemm256.hip (sc_gemm_common.h).
 #include "sc_gemm_common.h"
 #include <stdlib.h>
 
@@ -37,109 +37,61 @@ SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-// Epilogue straight from the accumulators (MFMA C layout: lane (li, lg) owns 4 consecutive columns of one row per
-// 16x16 block), no trip through LDS: fp32 outputs go out as 16-B stores (16 rows x 64 B per instruction); bf16
-// outputs are packed and widened to 16 B per lane with v_permlane16_swap (the odd 16-lane rows hand their block-2jp
-// quad to the even rows' neighbour and take the even rows' block-2jp+1 quad), 16 rows x 2 x 32 B per instruction.
-//   row(i) = rbase + (i >> 2) * rhi + (i & 3) * 16,  colj[j] = this lane's first column of block j.
+// bf16 epilogue through a small wave-private LDS strip (4 KiB: 32 rows x 128 B), four passes per 128x64 wave tile.
+// Why: a store instruction that writes whole 128-B lines (8 rows x 128 B) retires 3.7x faster than the 16 rows x 64 B
+// an accumulator-layout store touches (tools/micro/store_pattern.hip: 1.0 vs 3.8 us per 256x256 bf16 tile on one CU),
+// and an un-retired store holds back every later LDS-DMA of the same wave (vmcnt retires in order).  The accumulators
+// are packed to bf16 BEFORE the LDS trip (half the LDS bytes of the fp32 staging in sc_gemm_common.h), 16-B chunks
+// XOR-swizzled by row so the 8-B writes (2-way at worst) and 16-B reads spread over the banks.
+//   BF16 / BF16_BIAS: C = bf16(acc (+ bias));  GELU_PAIR: C = u = bf16(acc + bias), C2 = bf16(gelu(float(u))).
 template <int EPI>
-SC_DEVICE void epilogue_direct(f32x4 (&acc)[8][4], const GemmArgs& g, int z, int rbase, int rhi, const int (&colj)[4],
-                               int lg) {
-    constexpr bool kF32 = (EPI == SC_EPI_F32 || EPI == SC_EPI_F32_BIAS_RES);
-    constexpr bool kBias = (EPI == SC_EPI_F32_BIAS_RES || EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR);
+SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* strip, int row0, int col0, int lane) {
+    const int li = lane & 15, lg = lane >> 4;
+    constexpr bool kBias = (EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR);
     f32x4 bj[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         bj[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (kBias && g.bias && colj[j] < g.N) bj[j] = *reinterpret_cast<const f32x4*>(g.bias + colj[j]);
+        const int c = col0 + j * 16 + lg * 4;
+        if (kBias && g.bias && c < g.N) bj[j] = *reinterpret_cast<const f32x4*>(g.bias + c);
     }
-    if (kF32) {
-        float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.slab_stride;
-        // residual rows: a rolling window of 4 row-blocks x 4 column-blocks (16 KiB per wave) stays in flight
-        constexpr bool kRes = (EPI == SC_EPI_F32_BIAS_RES);
-        f32x4 r[kRes ? 4 : 1][4];
-        auto res_load = [&](int i, int j) {
-            const int row = rbase + (i >> 2) * rhi + (i & 3) * 16;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (g.res && row < g.M && colj[j] < g.N) v = *reinterpret_cast<const f32x4*>(g.res + (size_t)row * g.ldres + colj[j]);
-            return v;
-        };
-        if (kRes) {
+    bf16* C = reinterpret_cast<bf16*>(g.C);
+    bf16* C2 = reinterpret_cast<bf16*>(g.C2);
+    const int rr = lane >> 3, rc = lane & 7;                      // read side: row (+ 8 s), 16-B chunk
+    const int gcol = col0 + rc * 8;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+    for (int p = 0; p < 4; ++p) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r[i][j] = res_load(i, j);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = rbase + (i >> 2) * rhi + (i & 3) * 16;
+        for (int ib = 0; ib < 2; ++ib) {
+            const int r = ib * 16 + li;                           // strip row
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 v = acc[i][j];
-                if (kRes) {
-                    v += bj[j] + r[i & 3][j];
-                    if (i + 4 < 8) r[i & 3][j] = res_load(i + 4, j);
-                }
-                if (row < g.M && colj[j] < g.N) *reinterpret_cast<f32x4*>(C + (size_t)row * g.ldc + colj[j]) = v;
+                const f32x4 v = acc[p * 2 + ib][j] + bj[j];
+                const int chunk = (j * 2 + (lg >> 1)) ^ (r & 7);
+                *reinterpret_cast<u32x2*>(strip + r * 128 + chunk * 16 + (lg & 1) * 8) = sc_pack4(v[0], v[1], v[2], v[3]);
             }
         }
-    } else {
-        bf16* C = reinterpret_cast<bf16*>(g.C);
-        bf16* C2 = reinterpret_cast<bf16*>(g.C2);
-        const bool odd = (lg & 1) != 0;
-        // GELU' input (the pre-activation tensor, same layout as the output): the whole 128x64 tile in one burst of loads
-        constexpr bool kAux = (EPI == SC_EPI_BF16_DGELU);
-        u32x2 ax[kAux ? 8 : 1][4];
-        if (kAux) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = rbase + (i >> 2) * rhi + (i & 3) * 16;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ax[i][j] = (u32x2){0u, 0u};
-                    if (row < g.M && colj[j] < g.N)
-                        ax[i][j] = *reinterpret_cast<const u32x2*>(g.aux + (size_t)row * g.ldaux + colj[j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = rbase + (i >> 2) * rhi + (i & 3) * 16;
-            const bool rok = row < g.M;
-#pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                f32x4 v0 = acc[i][2 * jp] + bj[2 * jp], v1 = acc[i][2 * jp + 1] + bj[2 * jp + 1];
-                if (EPI == SC_EPI_BF16_DGELU) {
-                    union { u32x2 u; bf16x4 h; } x0, x1;
-                    x0.u = ax[i][2 * jp]; x1.u = ax[i][2 * jp + 1];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v0[k] *= sc_gelu_grad_fast((float)x0.h[k]);
-                        v1[k] *= sc_gelu_grad_fast((float)x1.h[k]);
-                    }
-                }
-                const u32x2 p0 = sc_pack4(v0[0], v0[1], v0[2], v0[3]), p1 = sc_pack4(v1[0], v1[1], v1[2], v1[3]);
-                const auto s0 = __builtin_amdgcn_permlane16_swap(p1[0], p0[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(p1[1], p0[1], false, false);
-                const int col = odd ? colj[2 * jp] - 4 : colj[2 * jp + 1];
-                const bool ok = rok && col < g.N;
-                if (ok) *reinterpret_cast<u32x4*>(C + (size_t)row * g.ldc + col) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int r = s4 * 8 + rr;
+            const u32x4 u = *reinterpret_cast<const u32x4*>(strip + r * 128 + ((rc ^ (r & 7)) << 4));
+            const int grow = row0 + p * 32 + r;
+            if (grow < g.M && gcol < g.N) {
+                *reinterpret_cast<u32x4*>(C + (size_t)grow * g.ldc + gcol) = u;
                 if (EPI == SC_EPI_GELU_PAIR) {
-                    union { u32x2 u; bf16x4 h; } u0, u1;
-                    u0.u = p0; u1.u = p1;
-                    float h0[4], h1[4];
+                    union { u32x4 w; bf16x8 h; } x;
+                    x.w = u;
+                    bf16x8 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        h0[k] = sc_gelu_fast((float)u0.h[k]);
-                        h1[k] = sc_gelu_fast((float)u1.h[k]);
-                    }
-                    const u32x2 q0 = sc_pack4(h0[0], h0[1], h0[2], h0[3]), q1 = sc_pack4(h1[0], h1[1], h1[2], h1[3]);
-                    const auto t0 = __builtin_amdgcn_permlane16_swap(q1[0], q0[0], false, false);
-                    const auto t1 = __builtin_amdgcn_permlane16_swap(q1[1], q0[1], false, false);
-                    if (ok) *reinterpret_cast<u32x4*>(C2 + (size_t)row * g.ldc2 + col) = (u32x4){t0[0], t1[0], t0[1], t1[1]};
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_gelu_fast((float)x.h[e]);
+                    *reinterpret_cast<bf16x8*>(C2 + (size_t)grow * g.ldc2 + gcol) = o;
                 }
             }
         }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -292,14 +244,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
-    // Epilogue.  Measured on the ViT-B/16 shapes (one box, interleaved): store-only bf16 epilogues are 3-4 % faster
-    // straight from the registers; the ones that also READ a tile (fp32 residual, GELU' input) or write fp32 are
-    // 6-14 % faster through LDS, where every access is a full 128/256-B row segment instead of 64 B.
-    if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS) {
-        int colj[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) colj[j] = n0 + wc * 64 + j * 16 + lg * 4;
-        epilogue_direct<EPI>(acc, g, z, m0 + wr * 128 + li, 64, colj, lg);
+    // Epilogue: bf16 outputs without an extra input tile go through the bf16 LDS strip (full-line stores, half the LDS
+    // bytes); the fp32-residual, GELU' and fp32 epilogues keep the fp32 staging shared with sc_gemm256.hip.
+    if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) {
+        epilogue_bf16_lds<EPI>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
     } else {
         const int mw = wr * 128;
         float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
@@ -339,7 +287,7 @@ int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
 // stream never stops at a tile boundary -- the first six half-tiles of the next tile are issued during the last K
 // tiles of the current one -- so a new tile starts without the DMA round trip, without a workgroup launch and without
 // waiting for the previous tile's stores to drain.  At a boundary the two wave groups re-align (one extra barrier
-// for waves 0-3), every wave writes its 128x64 result straight from the accumulators (epilogue_direct), and the
+// for waves 0-3), every wave writes its 128x64 result through its 4-KiB LDS strip behind the ring (epilogue_bf16_lds), and the
 // stagger is restored (one extra barrier for waves 4-7).  The epilogue's stores enter the vmcnt stream between two half-tile DMAs: the
 // three phases that follow allow for them in their counted waits (kind POSTEPI, interior tiles: every store is
 // issued); tiles that touch the M / N edge, where a fully masked store may be skipped, drain to zero instead.
@@ -454,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm8pp_kernel(const GemmArgs g, int t
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 15, lg = lane >> 4;
-    // stores one wave issues per interior tile (every lane in bounds): bf16 16 B / lane -> 16, two tensors -> 32
+    // stores one wave issues per interior tile (every lane in bounds): 4 passes x 4 full-line stores, two tensors -> 32
     constexpr int ESTORES = (EPI == SC_EPI_GELU_PAIR) ? 32 : 16;
 
     PStager S;
@@ -512,10 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm8pp_kernel(const GemmArgs g, int t
             const int m0 = tm * BM, n0 = tn * BN;
             if (wr == 0) __builtin_amdgcn_s_barrier();           // waves 0-3 wait for 4-7: groups aligned
             __builtin_amdgcn_sched_barrier(0);
-            int colj[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) colj[j] = n0 + wc * 64 + j * 16 + lg * 4;
-            epilogue_direct<EPI>(acc, g, 0, m0 + wr * 128 + li, 64, colj, lg);
+            epilogue_bf16_lds<EPI>(acc, g, smem + RING + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -534,11 +479,11 @@ int launch_persistent(const GemmArgs& g, int total_tiles, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8pp_kernel<EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, RING);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, RING + 8 * 4096);
         attr_done = true;
     }
     const int grid = total_tiles < 256 ? total_tiles : 256;
-    gemm8pp_kernel<EPI><<<grid, 512, RING, st>>>(g, total_tiles);
+    gemm8pp_kernel<EPI><<<grid, 512, RING + 8 * 4096, st>>>(g, total_tiles);
     SC_LAUNCH_CHECK();
     return 1;
 }
