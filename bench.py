@@ -88,14 +88,14 @@ def cpu_baseline(model_name: str, n_genes: int, B: int = 8, steps: int = 3):
 
 def pmc_traffic_nt():
     """HBM bytes per NT-GEMM launch from the committed rocprofv3 PMC passes (profiles/README.md); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.json")
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic_summary.json")
     try:
         d = json.load(open(path))
     except Exception:
         return None
     tot = n = 0
     for k, v in d.items():
-        if "gemm256_kernel<0," in k or "gemm8p_kernel" in k:
+        if k.startswith("gemm8p_kernel") or k.startswith("gemm8pp_kernel"):
             tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
             n += v["launches"]
     return round(tot / n) if n else None
@@ -138,7 +138,7 @@ def main():
 
     import functools
     import spatial_clip_amd  # noqa: F401
-    from spatial_clip_amd import comm, data, losses, module, net, ops, optim
+    from spatial_clip_amd import comm, data, losses, module, net, ops, optim, streams
 
     n = net.SpatialClipNet(args.model, None, n_genes=args.n_genes, seed=0)
     cfg = n.cfg
@@ -167,6 +167,10 @@ def main():
         batches.append({k: v.cuda() for k, v in b.items()})
 
     def step(i):
+        with streams.chain_stream():       # same stream role as Trainer.fit (high-priority chain, side-stream wgrads)
+            return step_(i)
+
+    def step_(i):
         loss = m.training_step(batches[i % 2], i)
         loss.backward()
         reducer.finish()
@@ -224,7 +228,7 @@ def main():
         dom = "gemm_nt"
         fl, sec, cnt = agg[dom]
         ach = fl / sec / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm8p_kernel (NT: forward + dgrad GEMMs)", "achieved": round(ach, 1),
+        roofline = {"bound": "mfma", "kernel": "gemm8p_kernel / gemm8pp_kernel (NT: forward + dgrad GEMMs)", "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": pmc_traffic_nt(), "launches_per_step": cnt // args.steps,
                     "avg_launch_us": round(sec / cnt * 1e6, 1), "flops_per_launch_avg": fl / cnt,

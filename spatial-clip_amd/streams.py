@@ -1,0 +1,34 @@
+"""HIP stream roles of a training step.
+
+The data-gradient chain (forward, dgrad GEMMs, attention / LayerNorm backward, optimiser) is the critical path; the
+weight-gradient GEMMs run on a side stream (towers.TransformerStack.backward).  Running the chain on a HIGH-priority
+stream makes the dispatcher hand free CUs to the chain first, so the side stream only takes what the chain leaves:
+measured +1.1 % pairs/s on ViT-B/16 (one MI355X, interleaved runs).  ``SC_CHAIN_PRIO=0`` keeps the caller's stream.
+"""
+import contextlib
+import os
+
+import torch
+
+_chain = {}
+
+
+@contextlib.contextmanager
+def chain_stream():
+    """Context: run the enclosed work on this device's high-priority chain stream, ordered after what the caller's
+    stream has enqueued so far; the caller's stream waits for it on exit."""
+    if os.environ.get("SC_CHAIN_PRIO", "1") == "0" or not torch.cuda.is_available():
+        yield None
+        return
+    dev = torch.cuda.current_device()
+    s = _chain.get(dev)
+    if s is None:
+        s = _chain[dev] = torch.cuda.Stream(priority=-1)
+    cur = torch.cuda.current_stream()
+    if cur == s:
+        yield s
+        return
+    s.wait_stream(cur)
+    with torch.cuda.stream(s):
+        yield s
+    cur.wait_stream(s)

@@ -204,7 +204,8 @@ class TransformerStack:
         overlap = os.environ.get("SC_OVERLAP", "1") == "1"
         main = torch.cuda.current_stream()
         if overlap and getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream()
+            # lowest priority the runtime offers: the side stream's workgroups should only take what the chain leaves
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("SC_SIDE_PRIO", "1")))
         side = self._side if overlap else main
         last_read = {}                                   # buffer id -> event recorded on the side stream
 

@@ -12,7 +12,7 @@ from typing import Any, Dict, Optional
 
 import torch
 
-from . import comm
+from . import comm, streams
 
 
 def _to_device(batch: Dict[str, Any], device) -> Dict[str, Any]:
@@ -66,10 +66,11 @@ class Trainer:
                 if i >= n_train or (self.max_steps != -1 and self.global_step >= self.max_steps):
                     break
                 batch = _to_device(batch, model.device)
-                loss = model.training_step(batch, i)
-                loss.backward()
-                reducer.finish()
-                opt.step(grad_scale=1.0 / W, max_norm=self.gradient_clip_val)
+                with streams.chain_stream():
+                    loss = model.training_step(batch, i)
+                    loss.backward()
+                    reducer.finish()
+                    opt.step(grad_scale=1.0 / W, max_norm=self.gradient_clip_val)
                 if sched is not None:
                     sched.step()
                 self.global_step += 1
