@@ -69,7 +69,10 @@ int sc_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
  * bf16 output feeding the next GEMM; mean/rstd [rows] saved for backward (may be NULL).
  * Backward: dres = (accumulate ? dres : 0) + LN'(dy); also writes the bf16 copy of the new dres (may be NULL),
  * dgamma, dbeta and colsum = column sums of the new dres (= bias gradient of the Linear that produced the
- * residual branch; may be NULL).  ws: sc_layernorm_bwd_ws_floats() floats.  d % 4 == 0, d <= 2048. */
+ * residual branch; may be NULL).  ws: sc_layernorm_bwd_ws_floats() floats.  d % 4 == 0, d <= 2048.
+ * dgamma == NULL defers the column reductions: the per-block partial sums stay in ws and
+ * sc_layernorm_bwd_reduce(ws, ...) finishes dgamma / dbeta / colsum later (any stream ordered after the first call;
+ * ws must stay untouched until then) -- these only feed the optimiser, not the data-gradient chain. */
 int sc_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
                      float* mean, float* rstd, int rows, int d, float eps, void* stream);
 long long sc_layernorm_bwd_ws_floats(int rows, int d);
@@ -77,6 +80,8 @@ int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, long long l
                      const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
                      long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum, float* ws,
                      int rows, int d, void* stream);
+int sc_layernorm_bwd_reduce(const float* ws, int rows, int d, float* dgamma, float* dbeta, float* colsum,
+                            void* stream);
 
 /* u = bf16(x + bias[n]), h = bf16(gelu_erf(u)) on a dense fp32 [rows, n]: epilogue of a split-K forward Linear
  * (gene-MLP fc1, K = 20k genes, M = batch: the K loop is split over the chip and reduced in fp32 first). */

@@ -376,7 +376,19 @@ extern "C" int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, 
     else if (nvv == 4) SC_LN_BWD(4); else SC_LN_BWD(8);
 #undef SC_LN_BWD
     SC_LAUNCH_CHECK();
+    if (dgamma == nullptr) return 0;      // deferred: the caller runs sc_layernorm_bwd_reduce (possibly on another stream)
     colvec_finalize_kernel<<<(3 * d + 63) / 64, 1024, 0, st>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_layernorm_bwd_reduce(const float* ws, int rows, int d, float* dgamma, float* dbeta, float* colsum,
+                                       void* stream) {
+    SC_CHECK(rows > 0 && d > 0 && ws != nullptr && dgamma != nullptr && dbeta != nullptr,
+             "sc_layernorm_bwd_reduce: bad arguments rows=%d d=%d", rows, d);
+    int nblk = (rows + 3) / 4;
+    if (nblk > 1024) nblk = 1024;
+    colvec_finalize_kernel<<<(3 * d + 63) / 64, 1024, 0, (hipStream_t)stream>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -148,14 +148,29 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows: int, d: int, ldx: Optiona
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, colsum, rows: int, d: int, *,
-                  accumulate: bool, lddy=None, ldx=None, lddres=None, lddbf=None):
+                  accumulate: bool, lddy=None, ldx=None, lddres=None, lddbf=None, ws=None, defer_reduce: bool = False):
+    """``defer_reduce``: leave the per-block partial sums of dgamma / dbeta / colsum in ``ws`` (caller-owned, at least
+    layernorm_bwd_ws_floats floats) and finish them with layernorm_bwd_reduce -- e.g. on the weight-gradient stream."""
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.float32, "x"); _req(dres, torch.float32, "dres")
     l = _lib.lib()
-    ws = workspace(l.sc_layernorm_bwd_ws_floats(rows, d), dy.device, "ln")
+    if ws is None:
+        if defer_reduce:
+            raise SpatialClipHipError("layernorm_bwd: defer_reduce needs a caller-owned workspace")
+        ws = workspace(l.sc_layernorm_bwd_ws_floats(rows, d), dy.device, "ln")
     check(l.sc_layernorm_bwd(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
                              gamma.data_ptr(), dres.data_ptr(), lddres or d, _ptr(dres_bf16), lddbf or d,
-                             int(accumulate), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(colsum), ws.data_ptr(), rows, d,
-                             _stream()), "sc_layernorm_bwd")
+                             int(accumulate), None if defer_reduce else dgamma.data_ptr(), dbeta.data_ptr(), _ptr(colsum),
+                             ws.data_ptr(), rows, d, _stream()), "sc_layernorm_bwd")
+
+
+def layernorm_bwd_ws_floats(rows: int, d: int) -> int:
+    return int(_lib.lib().sc_layernorm_bwd_ws_floats(rows, d))
+
+
+def layernorm_bwd_reduce(ws, dgamma, dbeta, colsum, rows: int, d: int):
+    _req(ws, torch.float32, "ws")
+    check(_lib.lib().sc_layernorm_bwd_reduce(ws.data_ptr(), rows, d, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(colsum),
+                                             _stream()), "sc_layernorm_bwd_reduce")
 
 
 def bias_gelu_pair(x, bias, u, h, rows: int, n: int):

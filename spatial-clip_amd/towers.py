@@ -229,6 +229,24 @@ class TransformerStack:
             if ev is not None:
                 main.wait_event(ev)
 
+        # LayerNorm backward: the token pass stays on the chain; the column reductions (dgamma, dbeta, the bias gradient
+        # of the Linear in front) feed only the optimiser, so with the side stream on they leave their partial sums in
+        # one of four rotating workspaces and are finished on the side stream
+        ln_ws_n = ops.layernorm_bwd_ws_floats(M, d)
+        ln_ws = [bf.get(f"ln_ws.{k}", (ln_ws_n,), F32) for k in range(4)] if overlap else None
+        ln_pos = [0]
+
+        def ln_bwd(dy, x, mean, rstd, gamma, g_bf, dgamma, dbeta, colsum) -> None:
+            if not overlap:
+                ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, g_bf, dgamma, dbeta, colsum, M, d, accumulate=True)
+                return
+            ws = ln_ws[ln_pos[0] % 4]
+            ln_pos[0] += 1
+            before_write(ws)
+            ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, g_bf, dgamma, dbeta, colsum, M, d, accumulate=True,
+                              ws=ws, defer_reduce=True)
+            on_side(lambda: ops.layernorm_bwd_reduce(ws, dgamma, dbeta, colsum, M, d), (ws,))
+
         dA = bf.get("dA", (M, d), BF16)
         dO = bf.get("dO", (M, d), BF16)
         delta = bf.get("delta", (B, H, L), F32)
@@ -266,9 +284,8 @@ class TransformerStack:
             rpos = (rpos + 1) % 3
             g1 = ring[rpos]
             before_write(g1)
-            ops.layernorm_bwd(dA, xmid, bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32),
-                              s.p(self._n(i, "ln_2.weight")), dres, g1, g("ln_2.weight"), g("ln_2.bias"),
-                              g("attn.out_proj.bias"), M, d, accumulate=True)
+            ln_bwd(dA, xmid, bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32),
+                   s.p(self._n(i, "ln_2.weight")), g1, g("ln_2.weight"), g("ln_2.bias"), g("attn.out_proj.bias"))
             # ---- attention branch: xmid = x_in + out_proj(attn(in_proj(ln_1(x_in))))
             ops.gemm(ops.NT, ops.EPI_BF16, g1, cp("attn.out_proj.weight").wb, dO, M=M, N=d, K=d)
             before_write(dqkv)
@@ -285,9 +302,8 @@ class TransformerStack:
             rpos = (rpos + 1) % 3
             g2 = ring[rpos]
             before_write(g2)
-            ops.layernorm_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
-                              s.p(self._n(i, "ln_1.weight")), dres, g2, g("ln_1.weight"), g("ln_1.bias"),
-                              prev_bias, M, d, accumulate=True)
+            ln_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
+                   s.p(self._n(i, "ln_1.weight")), g2, g("ln_1.weight"), g("ln_1.bias"), prev_bias)
             if on_layer_done is not None:
                 on_side(lambda i=i: on_layer_done(i), ())     # the bucket all-reduce follows the side stream
         if overlap:
