@@ -158,6 +158,12 @@ int sc_contrastive_loss_bwd(float* z_inout, int B, int G, const float* logit_sca
                             const float* grad_out, float* rowgrad, float* dscale, float* dbias, void* stream);
 /* RecallAtK (src/models/components/metrics.py:22-36) on the local [B,B] block of z[0]: hits3 += {R@1,R@5,R@10}. */
 int sc_recall_hits(const float* z_image_rows, int G, int B, int col0, int* hits3, void* stream);
+/* Validation-only zero-shot gene-expression metric (src/metrics/zero_shot.py:62-88): sample-wise
+ * Pearson correlation of pred[rows, cols] (image_features @ gene_bank^T) against the rank-weighted targets, rows with
+ * sqrt(sum pc^2) * sqrt(sum tc^2) <= 1e-6 score 0.  pcc[rows] (may be NULL); sum_count[0] += sum(pcc),
+ * sum_count[1] += rows (the metric's two states; may be NULL). */
+int sc_pcc_rows(const float* pred, long long ldp, const float* target, long long ldt, int rows, int cols, float* pcc,
+                float* sum_count, void* stream);
 /* logit_scale.exp() (src/models/components/spatial_clip_net.py:51) and its backward dx = dy * y * mult. */
 int sc_exp_scalar(const float* x, float* y, void* stream);
 int sc_exp_scalar_bwd(const float* y, const float* dy, float* dx, float mult, void* stream);

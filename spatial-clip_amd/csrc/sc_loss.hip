@@ -310,6 +310,45 @@ __global__ void exp_scalar_bwd_kernel(const float* __restrict__ y, const float* 
     *dx = (*dy) * (*y) * mult;
 }
 
+// ---------------------------------------------------------------------------------------------- zero-shot PCC rows
+// Sample-wise Pearson correlation between predicted gene logits and rank-weighted targets
+// (ref:src/metrics/zero_shot.py:72-88).  One workgroup per row, two passes over the row like the reference (means
+// first, then centred sums; the row comes from L2 the second time); rows with a denominator <= 1e-6 score 0.
+// sum_count[0] += sum of the rows' pcc, sum_count[1] += number of rows (float atomics: 2 per row).
+__global__ __launch_bounds__(256) void pcc_rows_kernel(const float* __restrict__ pred, long long ldp,
+                                                       const float* __restrict__ tgt, long long ldt, int cols,
+                                                       float* __restrict__ pcc, float* __restrict__ sum_count) {
+    __shared__ float red[3][4];
+    const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float* p = pred + (long long)row * ldp;
+    const float* q = tgt + (long long)row * ldt;
+    float sp = 0.f, sq = 0.f;
+    for (int c = t; c < cols; c += 256) { sp += p[c]; sq += q[c]; }
+    sp = sc_wave_sum(sp); sq = sc_wave_sum(sq);
+    if (lane == 0) { red[0][w] = sp; red[1][w] = sq; }
+    __syncthreads();
+    const float mp = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)cols;
+    const float mq = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)cols;
+    __syncthreads();
+    float num = 0.f, pp = 0.f, qq = 0.f;
+    for (int c = t; c < cols; c += 256) {
+        const float a = p[c] - mp, b = q[c] - mq;
+        num += a * b; pp += a * a; qq += b * b;
+    }
+    num = sc_wave_sum(num); pp = sc_wave_sum(pp); qq = sc_wave_sum(qq);
+    if (lane == 0) { red[0][w] = num; red[1][w] = pp; red[2][w] = qq; }
+    __syncthreads();
+    if (t == 0) {
+        const float n = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const float a = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const float b = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        const float den = sqrtf(a) * sqrtf(b);
+        const float r = den > 1e-6f ? n / den : 0.f;
+        if (pcc) pcc[row] = r;
+        if (sum_count) { atomicAdd(sum_count, r); atomicAdd(sum_count + 1, 1.0f); }
+    }
+}
+
 }  // namespace
 
 extern "C" int sc_sgemm_f32(const float* A, long long sam, long long sak, const float* B, long long sbn, long long sbk,
@@ -369,6 +408,14 @@ extern "C" int sc_contrastive_loss_bwd(float* z_inout, int B, int G, const float
                                                 nlab, rowstats, loss_out, temp_reg_weight, grad_out, rowgrad);
     SC_LAUNCH_CHECK();
     loss_scalar_grads_kernel<<<1, 256, 0, st>>>(rowgrad, 2 * B, dscale, dbias);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_pcc_rows(const float* pred, long long ldp, const float* target, long long ldt, int rows, int cols,
+                           float* pcc, float* sum_count, void* stream) {
+    SC_CHECK(rows > 0 && cols > 0 && ldp >= cols && ldt >= cols, "sc_pcc_rows: bad shape rows=%d cols=%d", rows, cols);
+    pcc_rows_kernel<<<rows, 256, 0, (hipStream_t)stream>>>(pred, ldp, target, ldt, cols, pcc, sum_count);
     SC_LAUNCH_CHECK();
     return 0;
 }

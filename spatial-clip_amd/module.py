@@ -7,12 +7,13 @@ loss kwargs, ``:44,55-61``), ``training_step(batch, batch_idx) -> loss``, ``vali
 from __future__ import annotations
 
 import inspect
+import os
 from typing import Any, Callable, Dict, Optional
 
 import torch
 
 from . import ops
-from .metrics import ContrastiveMetrics
+from .metrics import ContrastiveMetrics, ZeroShotGeneExpressionMetric
 from .net import SpatialClipNet
 
 
@@ -33,7 +34,8 @@ class SpatialClipLitModule(torch.nn.Module):
         self.val_metrics = val_metrics or ContrastiveMetrics("val/")
         self.test_metrics = test_metrics or ContrastiveMetrics("test/")
         self.global_hvg_path = global_hvg_path
-        self.zero_shot_metric = None            # validation-only, not on the training path
+        # validation-only zero-shot path (spatial_clip_module.py:36-41)
+        self.zero_shot_metric = ZeroShotGeneExpressionMetric(global_hvg_path=global_hvg_path) if global_hvg_path else None
         self.gene_bank_embeddings = None
         self.trainer = None
         self.logged: Dict[str, Any] = {}
@@ -85,17 +87,53 @@ class SpatialClipLitModule(torch.nn.Module):
         self.log_dict(self.train_metrics, on_step=False, on_epoch=True, sync_dist=True)
         return output["loss"]
 
+    def on_validation_start(self) -> None:
+        """Build the gene bank once: text-tower embeddings of every gene name in ``global_hvg_path``
+        (spatial_clip_module.py:73-103).  ``net.tokenizer`` must turn a list of gene names into token ids; the
+        built-in one does not tokenise strings (BPE is CPU-side data preparation), so a data module that wants this
+        metric installs its tokenizer on the net, as the reference's data module does."""
+        if not self.zero_shot_metric or self.gene_bank_embeddings is not None:
+            return
+        path = self.global_hvg_path
+        if not path or not os.path.exists(path):
+            print(f"Warning: Global HVG path {path} not found.")
+            return
+        with open(path, "r") as f:
+            gene_list = [line.strip() for line in f if line.strip()]
+        if not gene_list:
+            return
+        embs = []
+        with torch.no_grad():
+            for i in range(0, len(gene_list), 256):
+                tokens = self.net.tokenizer(gene_list[i:i + 256])
+                tokens = tokens.to(self.device) if isinstance(tokens, torch.Tensor) else torch.as_tensor(tokens).to(self.device)
+                embs.append(self.net.model.encode_text(tokens, normalize=True).float())
+        self.gene_bank_embeddings = torch.cat(embs, dim=0).contiguous()
+
+    def _zero_shot_update(self, batch: Dict[str, Any], output: Dict[str, torch.Tensor], name: str) -> None:
+        if self.zero_shot_metric and self.gene_bank_embeddings is not None and "raw_text" in batch:
+            f_i = output["image_features"].detach().float().contiguous()
+            bank = self.gene_bank_embeddings
+            B, D = f_i.shape
+            n = bank.shape[0]
+            logits = torch.empty((B, n), dtype=torch.float32, device=f_i.device)     # image_features @ bank.T
+            ops.sgemm(f_i, D, 1, bank, D, 1, logits, n, B, n, D)
+            self.zero_shot_metric.update(logits, batch["raw_text"])
+            self.log(name, self.zero_shot_metric, on_step=False, on_epoch=True, sync_dist=True)
+
     def validation_step(self, batch: Dict[str, Any], batch_idx: int) -> None:
         with torch.no_grad():
             output = self.model_step(batch, self.val_metrics)
         self.log("val/loss", output["loss"], on_step=False, on_epoch=True, prog_bar=True, sync_dist=True)
         self.log_dict(self.val_metrics, on_step=False, on_epoch=True, sync_dist=True)
+        self._zero_shot_update(batch, output, "val/zero_shot_pcc")
 
     def test_step(self, batch: Dict[str, Any], batch_idx: int) -> None:
         with torch.no_grad():
             output = self.model_step(batch, self.test_metrics)
         self.log("test/loss", output["loss"], on_step=False, on_epoch=True, sync_dist=True)
         self.log_dict(self.test_metrics, on_step=False, on_epoch=True, sync_dist=True)
+        self._zero_shot_update(batch, output, "test/zero_shot_pcc")
 
     def configure_optimizers(self) -> Dict[str, Any]:
         optimizer = self.hparams.optimizer_cfg(params=self.parameters())

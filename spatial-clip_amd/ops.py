@@ -155,7 +155,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, cols
     l = _lib.lib()
     if ws is None:
         if defer_reduce:
-            raise SpatialClipHipError("layernorm_bwd: defer_reduce needs a caller-owned workspace")
+            raise _lib.SpatialClipHipError("layernorm_bwd: defer_reduce needs a caller-owned workspace")
         ws = workspace(l.sc_layernorm_bwd_ws_floats(rows, d), dy.device, "ln")
     check(l.sc_layernorm_bwd(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
                              gamma.data_ptr(), dres.data_ptr(), lddres or d, _ptr(dres_bf16), lddbf or d,
@@ -338,3 +338,14 @@ def gather_rows(src, idx, L, dst, B, d):
 def scatter_rows(src, idx, L, dst, dst_bf16, B, d):
     check(_lib.lib().sc_scatter_rows_f32(src.data_ptr(), idx.data_ptr(), L, dst.data_ptr(), _ptr(dst_bf16), B, d,
                                          _stream()), "sc_scatter_rows_f32")
+
+
+def pcc_rows(pred: torch.Tensor, target: torch.Tensor, pcc: Optional[torch.Tensor] = None,
+             sum_count: Optional[torch.Tensor] = None) -> None:
+    """Row-wise Pearson correlation with the reference metric's guards (src/metrics/zero_shot.py:72-88)."""
+    _req(pred, torch.float32, "pred"); _req(target, torch.float32, "target")
+    rows, cols = pred.shape
+    if tuple(target.shape) != (rows, cols):
+        raise _lib.SpatialClipHipError(f"pcc_rows: pred {tuple(pred.shape)} vs target {tuple(target.shape)}")
+    check(_lib.lib().sc_pcc_rows(pred.data_ptr(), pred.stride(0), target.data_ptr(), target.stride(0), rows, cols,
+                                 _ptr(pcc), _ptr(sum_count), _stream()), "sc_pcc_rows")

@@ -83,6 +83,9 @@ class Trainer:
             val = datamodule.val_dataloader()
             n_val = self._limit(len(val), self.limit_val_batches)
             model.val_metrics.reset()
+            model.on_validation_start()
+            if model.zero_shot_metric:
+                model.zero_shot_metric.reset()
             vl = []
             for i, batch in enumerate(val):
                 if i >= n_val:
@@ -92,6 +95,8 @@ class Trainer:
             if vl:
                 rec["val/loss"] = float(torch.stack(vl).mean())
                 rec.update(model.val_metrics.compute())
+                if model.zero_shot_metric and model.gene_bank_embeddings is not None:
+                    rec["val/zero_shot_pcc"] = model.zero_shot_metric.compute()
             self.history.append(rec)
         self.callback_metrics = {k: v for k, v in self.history[-1].items() if isinstance(v, float)} if self.history else {}
 

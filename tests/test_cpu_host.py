@@ -112,3 +112,23 @@ def test_synthetic_batch_contract():
     dm = data.SyntheticSpatialDataModule(batch_size=4, image_size=32, n_genes=50)
     with pytest.raises(ValueError):
         dm.setup()
+
+
+def test_zero_shot_metric_host_targets_match_reference(golden_dir):
+    """The host half of ZeroShotGeneExpressionMetric (caption -> rank-weighted vector) against the reference's output."""
+    import json
+    import numpy as np
+    from spatial_clip_amd import metrics
+    j = json.load(open(os.path.join(golden_dir, "zero_shot_metric.json")))
+    z = np.load(os.path.join(golden_dir, "zero_shot_metric.npz"))
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write("\n".join(j["genes"]) + "\n")
+    m = metrics.ZeroShotGeneExpressionMetric(global_hvg_path=f.name)
+    os.unlink(f.name)
+    assert m.num_global_genes == len(j["genes"])
+    for i, caps in enumerate(j["captions"]):
+        t = m._compute_rank_weighted_vector(caps, "cpu")
+        assert torch.equal(t, torch.from_numpy(z[f"targets{i}"]))
+    assert metrics.ZeroShotGeneExpressionMetric(global_hvg_path="/nonexistent").num_global_genes == 0
+    assert m.compute() == 0.0

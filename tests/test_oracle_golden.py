@@ -162,3 +162,25 @@ def test_notebook_invariants():
     assert (q_it.argmax(1) == torch.arange(B) + r * B).all()
     assert q_it[0, 0] > 0 and abs(float(q_it[0, 0]) - 0.5 / 1.5) < 1e-6
     assert float(q_it[1].max()) == 1.0 and int((q_it[1] > 0).sum()) == 1
+
+
+def test_zero_shot_metric_oracle_matches_reference_class(golden_dir):
+    """Validation-only zero-shot PCC metric: the oracle restatement against the vectors produced by
+    the reference's own ZeroShotGeneExpressionMetric (tests/golden/make_golden_zero_shot.py): rank-weighted targets
+    bit-exact (unknown genes, empty caption, duplicates), per-batch running sums and compute()."""
+    import json
+    import os
+    import numpy as np
+    j = json.load(open(os.path.join(golden_dir, "zero_shot_metric.json")))
+    z = np.load(os.path.join(golden_dir, "zero_shot_metric.npz"))
+    tot, n = 0.0, 0
+    for i, caps in enumerate(j["captions"]):
+        t = O.zero_shot_targets(caps, j["genes"])
+        assert torch.equal(t, torch.from_numpy(z[f"targets{i}"]))
+        rows = O.zero_shot_pcc_rows(torch.from_numpy(z[f"preds{i}"]), t)
+        if i == 1:
+            assert float(rows[0]) == 0.0 and float(rows[1]) == 0.0      # empty caption / constant prediction
+        tot += float(rows.sum())
+        n += rows.numel()
+        assert abs(tot - j["sum_after"][i]) < 1e-6
+    assert n == j["total_count"] and abs(tot / n - j["compute"]) < 1e-7
