@@ -11,6 +11,7 @@ and writes parameter gradients directly into the flat gradient buffer (``p.grad`
 backward (the reference path never uses gradient accumulation)."""
 from __future__ import annotations
 
+import math
 import os
 from dataclasses import is_dataclass
 from typing import Any, Callable, Dict, List, Optional
@@ -49,6 +50,26 @@ class _NetFn(torch.autograd.Function):
     def backward(ctx, d_img, d_txt, d_s):
         ctx.net._backward(d_img, d_txt, d_s)
         return None, None, None, None
+
+
+def resize_pos_embed(state_dict: Dict[str, torch.Tensor], grid_size, interpolation: str = "bicubic",
+                     antialias: bool = True) -> None:
+    """Rescale the grid of visual position embeddings of a checkpoint to this model's patch grid when they differ
+    (``src/open_clip/model.py:792-823``; load-time host work): class token kept, grid bicubic-resampled with
+    antialiasing, ``align_corners=False``.  In place on ``state_dict['visual.positional_embedding']``."""
+    old = state_dict.get("visual.positional_embedding")
+    if old is None:
+        return
+    gh, gw = int(grid_size[0]), int(grid_size[1])
+    extra = 1
+    if gh * gw + extra == old.shape[0]:
+        return
+    tok, img = old[:extra], old[extra:]
+    og = int(math.sqrt(len(img)))
+    img = img.float().reshape(1, og, og, -1).permute(0, 3, 1, 2)
+    img = torch.nn.functional.interpolate(img, size=(gh, gw), mode=interpolation, antialias=antialias, align_corners=False)
+    img = img.permute(0, 2, 3, 1).reshape(gh * gw, -1)
+    state_dict["visual.positional_embedding"] = torch.cat([tok.float(), img], dim=0).to(old.dtype)
 
 
 class _ClipFacade:
@@ -109,7 +130,10 @@ class SpatialClipNet(torch.nn.Module):
     def _load_pretrained(self, pretrained: str) -> None:
         if os.path.isfile(pretrained):        # local checkpoint path branch of factory.py:418-421
             sd = torch.load(pretrained, map_location="cpu")
-            sd = sd.get("state_dict", sd)
+            sd = dict(sd.get("state_dict", sd))
+            if self.cfg.vision is not None:
+                g = self.cfg.vision.image_size // self.cfg.vision.patch_size
+                resize_pos_embed(sd, (g, g))
             self.store.load_state_dict({k: v for k, v in sd.items() if k in self.store.by_name}, strict=False)
             return
         # tags such as laion2b_s34b_b79k resolve to a hub download in the reference (pretrained.py:843,880-912)

@@ -132,3 +132,18 @@ def test_zero_shot_metric_host_targets_match_reference(golden_dir):
         assert torch.equal(t, torch.from_numpy(z[f"targets{i}"]))
     assert metrics.ZeroShotGeneExpressionMetric(global_hvg_path="/nonexistent").num_global_genes == 0
     assert m.compute() == 0.0
+
+
+def test_resize_pos_embed_matches_reference(golden_dir):
+    """Checkpoint interop: position-embedding grid resampling at load time against the reference's
+    resize_pos_embed (tests/golden/make_golden_pos_embed.py): down- and up-sampling, and the no-op case."""
+    import numpy as np
+    from spatial_clip_amd import net
+    z = np.load(os.path.join(golden_dir, "pos_embed_resize.npz"))
+    for gs in (4, 7, 14):
+        sd = {"visual.positional_embedding": torch.from_numpy(z["old"]).clone()}
+        net.resize_pos_embed(sd, (gs, gs))
+        torch.testing.assert_close(sd["visual.positional_embedding"], torch.from_numpy(z[f"grid{gs}"]), atol=1e-6, rtol=1e-6)
+    sd = {"other": torch.zeros(1)}
+    net.resize_pos_embed(sd, (4, 4))          # no visual embedding: untouched
+    assert list(sd) == ["other"]

@@ -325,3 +325,26 @@ def test_side_stream_weight_gradients_are_bit_identical(monkeypatch):
             for k in g:
                 assert torch.equal(g[k], other[k]), (mode, k)
         grads[mode + str(len(grads))] = g
+
+
+def test_pretrained_file_with_other_grid_is_resized(tmp_path):
+    """Checkpoint interop: a local state_dict trained at another resolution loads by reference key names and gets its
+    position-embedding grid resampled (model.py:792-823); every other tensor is taken as is."""
+    data, losses, mc, module, net, optim = _pkg()
+    cfg_a, _ = tiny_cfgs(64, 32, 2, 32, 8)        # 4 x 4 grid
+    cfg_b, _ = tiny_cfgs(64, 32, 2, 48, 8)        # 6 x 6 grid
+    a = net.SpatialClipNet("custom", None, model_cfg=cfg_a, seed=1)
+    perturb(a)
+    path = tmp_path / "a.pt"
+    torch.save({"state_dict": {k: v.cpu() for k, v in a.state_dict().items()}}, path)
+    b = net.SpatialClipNet("custom", str(path), model_cfg=cfg_b, seed=2)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sb["visual.positional_embedding"].shape == (37, 64)
+    want = {"visual.positional_embedding": sa["visual.positional_embedding"].cpu().clone()}
+    net.resize_pos_embed(want, (6, 6))
+    torch.testing.assert_close(sb["visual.positional_embedding"].cpu(), want["visual.positional_embedding"])
+    for k in sa:
+        if k != "visual.positional_embedding":
+            assert torch.equal(sa[k].cpu(), sb[k].cpu()), k
+    out = b(torch.randn(4, 3, 48, 48).cuda(), torch.randn(4, cfg_b.gene.n_genes).cuda())
+    assert torch.isfinite(out["image_features"]).all()
