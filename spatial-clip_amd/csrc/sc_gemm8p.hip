@@ -739,6 +739,7 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     if (persist && splitk == 1 && nblocks >= 1024 && ktiles >= 3) {      // >= 4 rounds of tiles (measured: +7 % at 7 rounds, -3 % at 2.3)
         if (epi == SC_EPI_BF16) return launch_persistent<SC_EPI_BF16>(g, nblocks, st);
         if (epi == SC_EPI_BF16_BIAS) return launch_persistent<SC_EPI_BF16_BIAS>(g, nblocks, st);
+        if (epi == SC_EPI_GELU_PAIR) return launch_persistent<SC_EPI_GELU_PAIR>(g, nblocks, st);      // +1.5 % at 9.2 rounds
     }
     int rc = 0;
 #define SC_CASE(EPI) \
