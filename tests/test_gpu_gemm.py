@@ -86,6 +86,12 @@ def test_nt_persistent_tile_walk_exact(K):
         assert torch.equal(out, ref.to(torch.bfloat16)), (K, rep)
         ops.gemm(ops.NT, ops.EPI_BF16_BIAS, a.cuda(), b.cuda(), out, M=M, N=N, K=K, bias=bias.cuda())
         assert torch.equal(out, (ref + bias.cuda()).to(torch.bfloat16)), (K, rep, "bias")
+        h = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+        a2 = (a.float() * 0.25).to(torch.bfloat16)               # keeps u in GELU's curved range; still exact sums
+        ops.gemm(ops.NT, ops.EPI_GELU_PAIR, a2.cuda(), b.cuda(), out, M=M, N=N, K=K, bias=bias.cuda(), out2=h)
+        u_ref = (a2.cuda().float() @ b.cuda().float().t() + bias.cuda()).to(torch.bfloat16)
+        assert torch.equal(out, u_ref), (K, rep, "gelu pair u")
+        torch.testing.assert_close(h.float(), gelu(u_ref.float()).to(torch.bfloat16).float(), atol=1e-2, rtol=1e-2)
 
 
 def test_nt_phase_interleaved_splitk_exact():
