@@ -18,6 +18,7 @@
 // on q.k, fp32 softmax, optional additive causal mask :1080-1086).
 #include "sc_common.h"
 #include "sc_kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -60,6 +61,37 @@ SC_DEVICE void load_images2(char* img_a, const bf16* src_a, long long stride_a, 
                 const int row = c / CH, ch = c % CH;
                 *reinterpret_cast<u32x4*>(img_a + Img<DH>::off(row, ch)) = va[u];
                 *reinterpret_cast<u32x4*>(img_b + Img<DH>::off(row, ch)) = vb[u];
+            }
+        }
+    }
+}
+
+// Four images (Q, K, V of one head out of the packed qkv rows, and dO) with every global load of a batch in flight
+// before the first LDS store: the fused backward kernel pays one memory round trip for all its LDS-resident operands.
+template <int DH>
+SC_DEVICE void load_images4(char* const (&img)[4], const bf16* const (&src)[4], const long long (&stride)[4], int L, int Lp,
+                            int t) {
+    constexpr int CH = DH / 8, NB = 3;
+    const int total = Lp * CH, step = blockDim.x;
+    for (int c0 = t; c0 < total; c0 += NB * step) {
+        u32x4 v[4][NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u * step;
+            const int row = c / CH, ch = c % CH;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k][u] = (u32x4){0u, 0u, 0u, 0u};
+                if (c < total && row < L) v[k][u] = *reinterpret_cast<const u32x4*>(src[k] + (long long)row * stride[k] + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u * step;
+            if (c < total) {
+                const int row = c / CH, ch = c % CH;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(img[k] + Img<DH>::off(row, ch)) = v[k][u];
             }
         }
     }
@@ -381,6 +413,189 @@ __global__ __launch_bounds__(1024) void attn_bwd_dkv_kernel(const bf16* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------- backward, fused
+// dQ, dK and dV of one (batch, head) in ONE workgroup: Q, K, V and dO all sit in LDS (4 x Lp x dh bf16 = 112 KiB at
+// L = 197, dh = 64; one workgroup per CU), loaded once.  Pass A (wave = query tile) is the dq kernel above with its
+// per-tile operands read from the LDS images and delta = rowsum(dO * O) left in LDS; pass B (wave = key tile) is the
+// dkv kernel.  Against the two-kernel form this reads qkv / dO once instead of twice and needs no delta round trip
+// through HBM (618 MB instead of 1.0 GB per ViT-B/16 layer at B = 256).  Same arithmetic, same results.
+template <int DH, bool CAUSAL>
+__global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                                const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                float* __restrict__ delta, bf16* __restrict__ dqkv, int L,
+                                                                int Lq, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = DH / 32, DT = DH / 16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int d = H * DH;
+    const long long rs = 3LL * d;
+    const bf16* base = qkv + (long long)b * L * rs + h * DH;
+    const int Lp = (L + 31) & ~31;
+    const int isz = Lp * DH * 2;
+    char* Qimg = smem;
+    char* Kimg = smem + isz;
+    char* Vimg = smem + 2 * isz;
+    char* Gimg = smem + 3 * isz;
+    float* slse = reinterpret_cast<float*>(smem + 4 * isz);
+    float* sdel = slse + Lp;
+    {
+        char* const imgs[4] = {Qimg, Kimg, Vimg, Gimg};
+        const bf16* const srcs[4] = {base, base + d, base + 2 * d, dout + (long long)b * L * d + h * DH};
+        const long long strides[4] = {rs, rs, rs, (long long)d};
+        load_images4<DH>(imgs, srcs, strides, L, Lp, t);
+    }
+    for (int i = t; i < Lp; i += blockDim.x) {
+        slse[i] = i < L ? -lse[((long long)b * H + h) * L + i] * 1.4426950408889634f : 0.f;
+        sdel[i] = 0.f;
+    }
+    __syncthreads();
+    const float c2 = scale * 1.4426950408889634f;
+    // ---------------- pass A: dQ (+ delta) ----------------
+    const int nqt = (Lq + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += nwaves) {
+        const int q = qt * 16 + li;
+        const int qc = min(q, L - 1);
+        bf16x8 qf[KS], dof[KS];
+        float dl = 0.f;
+        const bf16* orow = out + ((long long)b * L + qc) * d + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = frag_row<DH>(Qimg, qt * 16, ks, li, lg);
+            dof[ks] = frag_row<DH>(Gimg, qt * 16, ks, li, lg);
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + ks * 32 + lg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[e];
+        }
+        dl = quad_sum(dl);
+        const float nl2 = slse[qc];
+        if (q < Lq && lg == 0) {
+            sdel[q] = dl;
+            delta[((long long)b * H + h) * L + q] = dl;
+        }
+        f32x4 dq[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int kend = CAUSAL ? min(Lp, ((qt * 16 + 15) / 32 + 1) * 32) : Lp;
+        for (int k0 = 0; k0 < kend; k0 += 32) {
+            // all row fragments of the block in flight before the first MFMA, the transposed ones issued before the
+            // VALU section: two LDS round trips per block instead of one per fragment
+            bf16x8 ka[KS], kb[KS], va[KS], vb[KS], ktr[DT];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                ka[ks] = frag_row<DH>(Kimg, k0, ks, li, lg);
+                kb[ks] = frag_row<DH>(Kimg, k0 + 16, ks, li, lg);
+                va[ks] = frag_row<DH>(Vimg, k0, ks, li, lg);
+                vb[ks] = frag_row<DH>(Vimg, k0 + 16, ks, li, lg);
+            }
+            f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = sc_mfma16(ka[ks], qf[ks], s0);
+                s1 = sc_mfma16(kb[ks], qf[ks], s1);
+                p0 = sc_mfma16(va[ks], dof[ks], p0);
+                p1 = sc_mfma16(vb[ks], dof[ks], p1);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) ktr[dt] = frag_tr<DH>(Kimg, k0, dt * 16, li, lg);
+            const bool edge = (k0 + 32 > L) || CAUSAL;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pa = fast_exp2(fmaf(s0[r], c2, nl2)), pb = fast_exp2(fmaf(s1[r], c2, nl2));
+                if (edge) {
+                    const int ka = k0 + 4 * lg + r, kb = ka + 16;
+                    if (ka >= L || (CAUSAL && ka > q)) pa = 0.f;
+                    if (kb >= L || (CAUSAL && kb > q)) pb = 0.f;
+                }
+                s0[r] = pa * (p0[r] - dl);
+                s1[r] = pb * (p1[r] - dl);
+            }
+            const bf16x8 dsf = pack8(s0, s1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                dq[dt] = sc_mfma16(ktr[dt], dsf, dq[dt]);
+        }
+        if (q < Lq) {
+            bf16* drow = dqkv + ((long long)b * L + q) * rs + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                *reinterpret_cast<u32x2*>(drow + dt * 16 + lg * 4) =
+                    sc_pack4(dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale);
+        }
+    }
+    __syncthreads();                                  // every query's delta is in LDS
+    // ---------------- pass B: dK, dV ----------------
+    const int nkt = (L + 15) >> 4;
+    for (int kt = wave; kt < nkt; kt += nwaves) {
+        const int key = kt * 16 + li;
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = frag_row<DH>(Kimg, kt * 16, ks, li, lg);
+            vf[ks] = frag_row<DH>(Vimg, kt * 16, ks, li, lg);
+        }
+        f32x4 dk[DT], dv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dk[dt] = dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int qbeg = CAUSAL ? ((kt * 16) / 32) * 32 : 0;
+        for (int q0 = qbeg; q0 < ((Lq + 31) & ~31); q0 += 32) {
+            bf16x8 qa_[KS], qb_[KS], ga_[KS], gb_[KS], gtr[DT];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qa_[ks] = frag_row<DH>(Qimg, q0, ks, li, lg);
+                qb_[ks] = frag_row<DH>(Qimg, q0 + 16, ks, li, lg);
+                ga_[ks] = frag_row<DH>(Gimg, q0, ks, li, lg);
+                gb_[ks] = frag_row<DH>(Gimg, q0 + 16, ks, li, lg);
+            }
+            f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = sc_mfma16(qa_[ks], kf[ks], s0);
+                s1 = sc_mfma16(qb_[ks], kf[ks], s1);
+                p0 = sc_mfma16(ga_[ks], vf[ks], p0);
+                p1 = sc_mfma16(gb_[ks], vf[ks], p1);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) gtr[dt] = frag_tr<DH>(Gimg, q0, dt * 16, li, lg);     // lands under the VALU section
+            f32x4 pr0, pr1;
+            const bool edge = (q0 + 32 > Lq) || (kt * 16 + 16 > L) || CAUSAL;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qa = q0 + 4 * lg + r, qb = qa + 16;
+                float pa = fast_exp2(fmaf(s0[r], c2, slse[qa])), pb = fast_exp2(fmaf(s1[r], c2, slse[qb]));
+                float da = pa * (p0[r] - sdel[qa]), db = pb * (p1[r] - sdel[qb]);
+                if (edge) {
+                    const bool ma = (qa >= Lq || key >= L || (CAUSAL && key > qa));
+                    const bool mb = (qb >= Lq || key >= L || (CAUSAL && key > qb));
+                    pa = ma ? 0.f : pa; da = ma ? 0.f : da;
+                    pb = mb ? 0.f : pb; db = mb ? 0.f : db;
+                }
+                pr0[r] = pa;
+                pr1[r] = pb;
+                s0[r] = da;
+                s1[r] = db;
+            }
+            const bf16x8 pf = pack8(pr0, pr1), dsf = pack8(s0, s1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = sc_mfma16(gtr[dt], pf, dv[dt]);
+                dk[dt] = sc_mfma16(frag_tr<DH>(Qimg, q0, dt * 16, li, lg), dsf, dk[dt]);
+            }
+        }
+        if (key < L) {
+            bf16* drow = dqkv + ((long long)b * L + key) * rs + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                *reinterpret_cast<u32x2*>(drow + d + dt * 16 + lg * 4) =
+                    sc_pack4(dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale);
+                *reinterpret_cast<u32x2*>(drow + 2 * d + dt * 16 + lg * 4) =
+                    sc_pack4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+            }
+        }
+    }
+}
+
 template <typename K>
 void set_lds(K kern, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -433,6 +648,17 @@ extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, c
     hipStream_t st = (hipStream_t)stream;
     const int Lp = (L + 31) & ~31;
     const float scale = 1.0f / sqrtf((float)dh);
+    // fused single-kernel form when Q, K, V and dO of a head fit LDS together (L <= 304 at dh = 64)
+    static const bool fused_on = !(getenv("SC_ATTN_FUSED") && getenv("SC_ATTN_FUSED")[0] == '0');
+    const size_t lds_fused = (size_t)4 * Lp * dh * 2 + (size_t)2 * Lp * 4;
+    if (fused_on && lds_fused <= 160 * 1024) {
+        const size_t lds = lds_fused;
+        const int nthreads = attn_threads(L, 13);
+        SC_ATTN_DISPATCH(attn_bwd_fused_kernel, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta,
+                         (bf16*)dqkv, L, Lq, H, scale);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     const int nthreads = attn_threads(L, 7);
     {
         const size_t lds = (size_t)2 * Lp * dh * 2;

@@ -34,8 +34,10 @@ def ref_attn(qkv, B, L, H, dh, causal):
 
 @pytest.mark.parametrize("B,L,H,dh,causal", [(2, 197, 3, 64, False), (3, 17, 2, 32, False), (2, 13, 2, 32, True),
                                              (2, 77, 8, 64, True), (1, 257, 2, 64, False), (4, 16, 2, 32, True),
-                                             (2, 64, 1, 64, False)])
+                                             (2, 64, 1, 64, False), (1, 320, 2, 64, False), (1, 310, 1, 64, True)])
 def test_attention_fwd_bwd(B, L, H, dh, causal):
+    # L <= 304 (dh = 64) takes the fused backward kernel (Q, K, V, dO of a head in LDS together), longer sequences the
+    # dq + dkv pair
     ops = _ops()
     g = torch.Generator().manual_seed(L + dh)
     d = H * dh
