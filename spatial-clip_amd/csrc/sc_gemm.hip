@@ -228,12 +228,9 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     g.aux = (const bf16*)aux; g.ldaux = ldaux;
     g.colsum = nullptr; g.tile_offset = 0;
     // kernel choice: 256x256 phase-interleaved kernel (NT) -> 256x256 two-stage LDS-DMA kernel (TN, and NT when
-    // pinned) -> 128x128 general kernel.  SC_GEMM_FORCE = 128 | 256 | p3 | s4 pins one kernel for A/B benchmarking
-    // (p3 = 256x128 3-stage two-workgroups-per-CU, s4 = 4-stage ring: both measured slower).
+    // pinned) -> 128x128 general kernel.  SC_GEMM_FORCE = 128 | 256 pins one kernel for A/B benchmarking.
     static const char* force = getenv("SC_GEMM_FORCE");
     int took = 0;
-    if (force && force[0] == 'p') took = sc_gemm_p3_try(mode, epi, g, splitk, slabs, st);
-    if (force && force[0] == 's') took = sc_gemm_s4_try(mode, epi, g, splitk, slabs, st);
     if (!force) took = sc_gemm8p_try(mode, epi, g, splitk, slabs, st);
     if (took == 0 && (!force || force[0] == '2')) {
         g.C = C;

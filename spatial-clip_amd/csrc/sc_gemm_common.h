@@ -1,5 +1,5 @@
 // Shared pieces of the MFMA GEMM kernels (128x128 general kernel in sc_gemm.hip, 256x256 LDS-DMA kernel in
-// sc_gemm256.hip, 256x128 3-stage kernel in sc_gemm_p3.hip): argument block and the fused epilogue that drains a
+// sc_gemm256.hip, phase-interleaved kernels in sc_gemm8p.hip): argument block and the fused epilogue that drains a
 // wave's 64x64 fp32 tile from LDS.
 //
 // Epilogue memory-level parallelism: the extra epilogue INPUT of a 64x64 sub-tile (fp32 residual rows, or the bf16
@@ -170,9 +170,5 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
 
 // 256x256 LDS-DMA kernel (sc_gemm256.hip): returns 1 if it took the problem, 0 if not eligible, <0 on error
 int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, float* c_final, hipStream_t st);
-// 256x128x32 3-stage kernel, two workgroups per CU (sc_gemm_p3.hip): same contract
-int sc_gemm_p3_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
-// 256x256x32 4-stage ring variant (sc_gemm_s4.hip): same contract
-int sc_gemm_s4_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
 // 256x256x64 phase-interleaved (ping-pong) kernel, NT only (sc_gemm8p.hip)
 int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
