@@ -148,6 +148,11 @@ SC_DEVICE float quad_sum(float v) {
 // raw v_exp_f32 (2^x): arguments here are <= 0 or moderately positive; results below the normal range flush to 0,
 // which is what a masked / far-below-max probability should be (exp2f() adds 5 range-fixup instructions per call)
 SC_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// 2^(x * c + b) on four values: the affine part as packed f32 math (v_pk_fma_f32), then four v_exp_f32
+SC_DEVICE f32x4 exp2_affine(f32x4 x, float c, float b) {
+    const f32x4 a = x * c + b;
+    return (f32x4){fast_exp2(a[0]), fast_exp2(a[1]), fast_exp2(a[2]), fast_exp2(a[3])};
+}
 
 // ---------------------------------------------------------------------------------------------- forward
 template <int DH, bool CAUSAL>
@@ -213,13 +218,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(7, 8))) vo
             mx = quad_max(mx);
             const float mn = fmaxf(m, mx);
             const float nb = -mn * c2;                      // exp(scale*(s - mn)) = exp2(s*c2 + nb)
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s0[r] = fast_exp2(fmaf(s0[r], c2, nb));
-                s1[r] = fast_exp2(fmaf(s1[r], c2, nb));
-                ps += s0[r] + s1[r];
-            }
+            s0 = exp2_affine(s0, c2, nb);
+            s1 = exp2_affine(s1, c2, nb);
+            const f32x4 pv = s0 + s1;
+            const float ps = (pv[0] + pv[1]) + (pv[2] + pv[3]);
             const bf16x8 pf = pack8(s0, s1);
             if (__any(mn != m)) {                           // running max moved for some query: rescale (rare after
                 const float alpha = fast_exp2((m - mn) * c2);   // the first blocks), otherwise alpha == 1 exactly
@@ -500,17 +502,17 @@ __global__ __launch_bounds__(1024) void attn_bwd_fused_kernel(const bf16* __rest
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) ktr[dt] = frag_tr<DH>(Kimg, k0, dt * 16, li, lg);
             const bool edge = (k0 + 32 > L) || CAUSAL;
+            f32x4 e0 = exp2_affine(s0, c2, nl2), e1 = exp2_affine(s1, c2, nl2);
+            if (edge) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pa = fast_exp2(fmaf(s0[r], c2, nl2)), pb = fast_exp2(fmaf(s1[r], c2, nl2));
-                if (edge) {
+                for (int r = 0; r < 4; ++r) {
                     const int ka = k0 + 4 * lg + r, kb = ka + 16;
-                    if (ka >= L || (CAUSAL && ka > q)) pa = 0.f;
-                    if (kb >= L || (CAUSAL && kb > q)) pb = 0.f;
+                    if (ka >= L || (CAUSAL && ka > q)) e0[r] = 0.f;
+                    if (kb >= L || (CAUSAL && kb > q)) e1[r] = 0.f;
                 }
-                s0[r] = pa * (p0[r] - dl);
-                s1[r] = pb * (p1[r] - dl);
             }
+            s0 = e0 * (p0 - dl);
+            s1 = e1 * (p1 - dl);
             const bf16x8 dsf = pack8(s0, s1);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
