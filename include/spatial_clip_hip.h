@@ -58,7 +58,7 @@ int sc_gemm_wgrad_bias(const void* dY, int lddy, const void* X, int ldx, int M, 
  * sc_attn_bwd writes dqkv[B*L, 3*H*dh] (bf16) and uses delta[B,H,L] as scratch.  L <= 320, dh in {32, 64}.
  * q_rows > 0 restricts the work to the first q_rows query positions of every sequence (the last ViT block only
  * feeds the CLS token downstream): outputs / dq of the other rows are not written, dk / dv receive only those
- * queries' contributions (dout of the unused rows is never read). */
+ * queries' contributions; dout / out of the unused rows may hold any FINITE values (they meet exact zeros only). */
 int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dh, int causal, int q_rows,
                 void* stream);
 int sc_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,

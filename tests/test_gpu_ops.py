@@ -84,6 +84,46 @@ def test_layernorm_fwd_bwd(rows, d):
         torch.testing.assert_close(dg.cpu(), gr.grad, atol=1e-3, rtol=1e-4)
         torch.testing.assert_close(db.cpu(), br.grad, atol=1e-3, rtol=1e-4)
         torch.testing.assert_close(cs.cpu(), want.sum(0), atol=2e-3, rtol=1e-4)
+        # deferred column reductions (weight-gradient stream form): same bits as the one-call form
+        dres2 = dres0.clone().cuda()
+        dg2 = torch.full((d,), 9.0, device=dev); db2 = torch.full((d,), 9.0, device=dev); cs2 = torch.full((d,), 9.0, device=dev)
+        ws = torch.empty(ops.layernorm_bwd_ws_floats(rows, d), device=dev)
+        ops.layernorm_bwd(dy.cuda(), x.cuda(), mean, rstd, gamma.cuda(), dres2, dbf, dg2, db2, cs2, rows, d, accumulate=acc,
+                          ws=ws, defer_reduce=True)
+        assert float(dg2[0]) == 9.0                      # untouched until the reduce call
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.layernorm_bwd_reduce(ws, dg2, db2, cs2, rows, d)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(dres2, dres) and torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(cs2, cs)
+
+
+def test_attention_cls_query_only():
+    """q_rows = 1 (the last ViT block feeds only the CLS token on): outputs / dq of the other rows are not written, dk / dv
+    get the CLS query's contribution only, and dout of the unused rows (any finite value) does not matter."""
+    ops = _ops()
+    B, L, H, dh = 3, 50, 2, 64
+    d = H * dh
+    g = torch.Generator().manual_seed(9)
+    qkv = bf(torch.randn(B * L, 3 * d, generator=g))
+    dout = bf(torch.randn(B * L, d, generator=g))
+    x = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = ref_attn(x, B, L, H, dh, False)
+    cls = torch.arange(B) * L
+    (o_ref[cls] * dout.float()[cls]).sum().backward()
+    out = torch.full((B * L, d), 5.0, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, L, device="cuda")
+    ops.attn_fwd(qkv.cuda(), B, L, H, dh, False, out=out, lse=lse, q_rows=1)
+    torch.testing.assert_close(out.float().cpu()[cls], o_ref.detach()[cls], atol=2e-2, rtol=2e-2)
+    keep = torch.ones(B * L, dtype=torch.bool); keep[cls] = False
+    assert bool((out.cpu()[keep] == 5.0).all())
+    dout_dev = dout.clone()
+    dout_dev[keep] = 1.0e4                               # finite garbage: multiplied by exact zeros only
+    out_in = out.clone(); out_in[keep.cuda()] = 0
+    dqkv = torch.zeros(B * L, 3 * d, dtype=torch.bfloat16, device="cuda")
+    ops.attn_bwd(qkv.cuda(), out_in, dout_dev.cuda(), lse, B, L, H, dh, False, dqkv=dqkv, q_rows=1)
+    torch.testing.assert_close(dqkv.float().cpu(), x.grad, atol=4e-2, rtol=4e-2)
 
 
 def test_layernorm_strided_rows():
