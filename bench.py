@@ -61,29 +61,83 @@ def host_cpu_share() -> int:
     return max(1, min(n, int(os.environ.get("SC_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(model_name: str, n_genes: int, B: int = 8, steps: int = 3):
-    """The oracle's fp32 train step timed on the host cores (reported baseline only)."""
+def cpu_model_string() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def _oracle_cfg(cfg):
+    from oracle import spatial_clip_oracle as O
+    v = cfg.vision
+    return O.ModelCfg(cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
+                      O.GeneCfg(cfg.gene.n_genes, cfg.gene.hidden))
+
+
+def cpu_baseline_leg(model_name: str, n_genes: int, B: int, steps: int = 3, loss: str = "clip"):
+    """The oracle's fp32 train step (fwd + loss + bwd + clip + AdamW + scheduler) timed on the host cores."""
     import torch
     from oracle import spatial_clip_oracle as O
     import spatial_clip_amd  # noqa: F401
     from spatial_clip_amd import data, model_configs as mc
     cfg = mc.get_model_config(model_name, n_genes)
-    v = cfg.vision
-    ocfg = O.ModelCfg(cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
-                      O.GeneCfg(cfg.gene.n_genes, cfg.gene.hidden))
+    ocfg = _oracle_cfg(cfg)
     cores = host_cpu_share()
     torch.set_num_threads(cores)
-    tr = O.OracleTrainer(ocfg, O.init_params(ocfg, seed=0), loss="clip", lr=1e-3, warmup=2000)
+    tr = O.OracleTrainer(ocfg, O.init_params(ocfg, seed=0), loss=loss, lr=1e-3, warmup=2000)
     rates = data.make_gene_rates(n_genes)
     times = []
     for s in range(steps + 1):
-        batch = data.synthetic_batch(B, v.image_size, n_genes, 8, s, gene_rates=rates)
+        batch = data.synthetic_batch(B, cfg.vision.image_size, n_genes, 8, s, gene_rates=rates)
         t0 = time.time()
         tr.training_step(batch)
         times.append(time.time() - t0)
-    best = min(times[1:])
-    return {"value": B / best, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 train step ({model_name}, n_genes={n_genes}), B={B}, 1 warm-up + {steps} timed steps, best"}
+    timed = sorted(times[1:])
+    return {"workload": f"{model_name}, n_genes={n_genes}, B={B}", "pairs_per_s_best": round(B / timed[0], 3),
+            "pairs_per_s_median": round(B / timed[len(timed) // 2], 3), "step_s": [round(t, 3) for t in times]}
+
+
+def cpu_baseline(model_name: str, n_genes: int):
+    """Reported baseline only (SURVEY.md 8d / BASELINE.md section 4): the oracle restatement of the identical
+    training_step on the GPU box's host cores, cfg [0] (ViT-Ti/16 + 2-layer gene-MLP, B = 8) and the bench model at a
+    reduced batch (B = 32), 1 warm-up + 3 timed steps each."""
+    legs = [cpu_baseline_leg("ViT-Ti-16-gene", n_genes, 8), cpu_baseline_leg(model_name, n_genes, 32)]
+    head = legs[1]
+    return {"value": head["pairs_per_s_best"], "unit": "pairs/s", "cores": host_cpu_share(), "kind": "port",
+            "cpu_model": cpu_model_string(),
+            "sample": f"oracle fp32 train step ({head['workload']}), 1 warm-up + 3 timed steps, best; "
+                      f"configs[0] leg ({legs[0]['workload']}) alongside",
+            "legs": legs}
+
+
+def loss_delta_vs_oracle(m, n, cfg, batch_cpu, loss_kind: str):
+    """Half of BASELINE's metric: |loss(HIP, bf16-mixed) - loss(fp32 oracle)| on the SAME batch and the SAME weights at
+    the benchmark's own size, outside the timed region (oracle forward only: ~10 s of host time at B = 256)."""
+    import torch
+    from oracle import spatial_clip_oracle as O
+    torch.set_num_threads(host_cpu_share())
+    with torch.no_grad():
+        out = m.model_step({k: v.cuda() for k, v in batch_cpu.items()})
+        torch.cuda.synchronize()
+        hip_loss = float(out["loss"])
+        f_i, f_t = out["image_features"].float().cpu(), out["text_features"].float().cpu()
+        p = {k: v.detach().cpu() for k, v in n.state_dict().items()}
+        f = O.net_forward(batch_cpu["images"], batch_cpu["texts"], p, _oracle_cfg(cfg))
+        if loss_kind == "clip":
+            ref = O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"])
+        else:
+            ref = O.spatial_loss(f["image_features"], f["text_features"], f["logit_scale"], batch_cpu["image_tile_ids"],
+                                 batch_cpu["text_tile_ids"], batch_cpu["neighbor_tile_ids"], batch_cpu["neighbor_alphas"])
+    return {"loss_hip": hip_loss, "loss_oracle_fp32": float(ref),
+            "loss_delta_vs_oracle": abs(hip_loss - float(ref)),
+            "max_abs_feature_delta": max(float((f_i - f["image_features"]).abs().max()),
+                                         float((f_t - f["text_features"]).abs().max())),
+            "batch": int(batch_cpu["images"].shape[0]), "tolerance": 1e-3}
 
 
 def pmc_traffic_nt():
@@ -99,6 +153,27 @@ def pmc_traffic_nt():
             tot += (v["fetch_bytes_corrected"] + v["write_bytes"]) * v["launches"]
             n += v["launches"]
     return round(tot / n) if n else None
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU)
+    BEFORE this process makes any GPU call, and return their exit code.  Rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()          # counts devices without initialising the GPU
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def note(msg):
@@ -122,23 +197,25 @@ def main():
     ap.add_argument("--loss", default="clip", choices=["clip", "spatial"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-loss-delta", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_env:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env}", file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-
     import functools
     import spatial_clip_amd  # noqa: F401
     from spatial_clip_amd import comm, data, losses, module, net, ops, optim, streams
+    rank, local_rank, world = comm.init_from_env(expect_world=args.gpus)     # set_device(LOCAL_RANK) + RCCL group
+    if world > 1 and dist.get_world_size() != args.gpus:
+        print(f"bench.py: live process group has {dist.get_world_size()} ranks, wanted {args.gpus}", file=sys.stderr)
+        sys.exit(2)
 
     n = net.SpatialClipNet(args.model, None, n_genes=args.n_genes, seed=0)
     cfg = n.cfg
@@ -157,7 +234,7 @@ def main():
     oc = m.configure_optimizers()
     opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
     reducer = comm.GradBucketReducer(n.store.grad)
-    n.grad_bucket_hook = reducer.bucket_ready if world > 1 else None
+    n.grad_bucket_hook = reducer.bucket_ready if comm.is_dist() else None
 
     B = args.batch
     rates = data.make_gene_rates(args.n_genes)
@@ -275,6 +352,12 @@ def main():
                                   "note": "flops_per_pair = reference-algorithmic (SURVEY 8d); executed excludes the "
                                           "last block's dead non-CLS token work that this build skips"}
 
+    delta = None
+    if rank == 0 and world == 1 and not args.no_loss_delta:
+        note("loss delta vs the fp32 oracle on one benchmark batch (oracle forward on the host)")
+        delta = loss_delta_vs_oracle(m, n, cfg, data.synthetic_batch(B, cfg.vision.image_size, args.n_genes, 8, 0, 0, 1,
+                                                                     rates), args.loss)
+        note(f"loss delta {delta['loss_delta_vs_oracle']:.2e}, max feature delta {delta['max_abs_feature_delta']:.2e}")
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -290,10 +373,12 @@ def main():
                                       f"{'ClipLoss' if args.loss == 'clip' else 'SpatialLoss(k=8)'} over global batch {G}, "
                                       "fwd+bwd+grad-allreduce+clip+AdamW", "global_batch": G,
                           "parallelism": f"dp{world}", "loss": float(loss.detach())},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "n_gpus_live": dist.get_world_size() if world > 1 else 1,
+               "loss_delta_vs_oracle": None if delta is None else delta["loss_delta_vs_oracle"],
+               "max_abs_feature_delta": None if delta is None else delta["max_abs_feature_delta"],
+               "parity": delta, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    comm.shutdown()
 
 
 if __name__ == "__main__":

@@ -136,7 +136,7 @@ int sc_scatter_rows_f32(const float* src, const int* idx, int L, float* dst, voi
 /* ------------------------------------------------------------------------------------------------ contrastive head
  * ClipLoss (src/open_clip/loss.py:91-155, local_loss layout) and SpatialLoss
  * (src/models/components/losses.py:44-124) on the device.  z[2][B][G] holds the cosine similarities
- * (z[0] = image_features . all_text^T, z[1] = text_features . all_image^T), produced with sc_sgemm_f32.
+ * (z[0] = image_features . all_text^T, z[1] = text_features . all_image^T), produced with sc_sgemm_f32(_grouped).
  * Soft labels are sparse: lab_col/lab_w[2][B][nlab] ((column, weight) pairs, column -1 = unused); they come from
  * sc_onehot_labels (ClipLoss: arange(B)+B*rank, loss.py:94-96) or sc_neighbor_join (SpatialLoss label loop,
  * losses.py:91-111: id -> LAST index, alpha*scale <= 0 skipped, L1-normalised).
@@ -145,6 +145,23 @@ int sc_scatter_rows_f32(const float* src, const int* idx, int L, float* dst, voi
  * scale) and d logit_bias; feature grads are then two sc_sgemm_f32 calls per direction. */
 int sc_sgemm_f32(const float* A, long long sam, long long sak, const float* B, long long sbn, long long sbk,
                  float* C, long long ldc, int M, int N, int K, int accumulate, void* stream);
+/* The same GEMM for up to SC_SGEMM_MAX_GROUP independent problems in ONE launch (flat tile list): the two similarity
+ * matrices of the forward, the four gradient products of the backward.  C[m][n] (+)= sum_k A[m*sam + k*sak] *
+ * B[n*sbn + k*sbk]; exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32).  Each operand needs one unit stride;
+ * `descs` is a HOST array. */
+#define SC_SGEMM_MAX_GROUP 6
+typedef struct {
+    const float* A; long long sam; long long sak;
+    const float* B; long long sbn; long long sbk;
+    float* C; long long ldc;
+    int M; int N; int K; int accumulate;
+} sc_sgemm_desc;
+int sc_sgemm_f32_grouped(const sc_sgemm_desc* descs, int n, void* stream);
+/* Send buffer of the feature all-gather (gather_features, src/open_clip/loss.py:21-65 + the tile-id gathers of
+ * src/models/components/losses.py:63-68, as ONE payload): out[r] = feat[r][0..D) | ids_a[r] | ids_b[r] (each int64 as
+ * two float slots; ids may both be NULL).  D and ldo even when ids are given. */
+int sc_pack_rows(const float* feat, long long ldf, const long long* ids_a, const long long* ids_b, float* out,
+                 long long ldo, int B, int D, void* stream);
 int sc_neighbor_join(const long long* all_image_tile_ids, const long long* all_text_tile_ids,
                      const long long* neighbor_tile_ids, const float* neighbor_alphas, int B, int G, int K, int rank,
                      float neighbor_alpha_scale, int* lab_col, float* lab_w, void* stream);

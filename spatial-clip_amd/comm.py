@@ -1,25 +1,42 @@
 """Data-parallel exchange steps of the training step over ``torch.distributed`` (backend "nccl" == RCCL over
 xGMI on ROCm; "gloo" on CPU for the world_size-2 correctness tests).  One process per GPU.
 
+Process bootstrap (reference: Lightning ``strategy: ddp`` creates the group inside ``trainer.fit``,
+configs/trainer/ddp.yaml:4, src/train.py:102,119; legacy loop src/open_clip_train/distributed.py:93-195):
+  init_from_env()         reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun), binds this process to
+                          cuda:LOCAL_RANK *before* anything allocates, and creates the RCCL process group.
+
 Collectives of the path:
-  C1+C3  gather_packed     ONE all-gather of image_features | text_features | tile ids packed per row
+  C1+C3  FeatureGather     the overlapped form used by the product: the second tower's features | tile ids are packed
+                           by one HIP kernel and all-gathered on a dedicated communication stream while the vision
+                           tower still runs; the image features follow and travel while the first similarity GEMM
+                           (which does not need them) computes.  Event hand-off, no host synchronisation.
+         gather_packed     the synchronous one-collective form (tests, and the fallback when nothing was prefetched)
                            (reference: 2x torch.distributed.nn.all_gather + 2x dist.all_gather,
                            src/open_clip/loss.py:50-52, src/models/components/losses.py:63-68)
   C1'    reduce_scatter_sum  autograd of the feature all-gather: sum over ranks of d(all_features), keep own rows
   C4     GradBucketReducer   bucketed SUM all-reduce of the flat fp32 gradient buffer, launched per layer while
                            backward is still running (RCCL runs on its own stream; the 1/world_size of DDP's mean
                            is folded into the optimiser's grad_scale)
-All functions are device-agnostic (CUDA/HIP or CPU tensors) and degrade to no-ops at world_size 1."""
+All functions are device-agnostic (CUDA/HIP or CPU tensors) and degrade to no-ops at world_size 1
+(``SC_FORCE_DIST=1`` keeps the collective code path alive on a 1-rank group: used to exercise RCCL on a 1-GPU box)."""
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
 
+def _force() -> bool:
+    return os.environ.get("SC_FORCE_DIST", "0") == "1"
+
+
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _force()
 
 
 def world() -> Tuple[int, int]:
@@ -28,10 +45,77 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) as the launcher exported them (torchrun / torch.distributed.run)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_from_env(backend: Optional[str] = None, expect_world: Optional[int] = None) -> Tuple[int, int, int]:
+    """Bind this process to its GPU and join the job's process group; idempotent.  Returns (rank, local_rank, world).
+
+    Must run before the model is built: ``SpatialClipNet`` allocates on the *current* device.  ``expect_world``
+    (e.g. ``trainer.devices * num_nodes``) must match what the launcher started, otherwise this raises instead of
+    silently training W independent replicas."""
+    rank, local_rank, W = env_world()
+    if expect_world is not None and expect_world != W:
+        raise RuntimeError(
+            f"the configuration asks for {expect_world} ranks but the launcher started WORLD_SIZE={W}: launch with "
+            f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {expect_world} --master-addr 127.0.0.1 ...` "
+            "(one process per GPU)")
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        n_dev = torch.cuda.device_count()
+        # several ranks may share one device only in the gloo rehearsal tests (SC_DIST_BACKEND=gloo)
+        torch.cuda.set_device(local_rank % max(n_dev, 1))
+    if W > 1 or _force():
+        if not dist.is_initialized():
+            backend = backend or os.environ.get("SC_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            kw = {}
+            if backend == "nccl":
+                if local_rank >= torch.cuda.device_count():
+                    raise RuntimeError(f"LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPUs are visible")
+                kw["device_id"] = torch.device(f"cuda:{local_rank}")      # eager RCCL communicator on this GPU
+            dist.init_process_group(backend, rank=rank, world_size=W, **kw)
+        elif dist.get_world_size() != W or dist.get_rank() != rank:
+            raise RuntimeError(f"live process group is rank {dist.get_rank()}/{dist.get_world_size()} but the "
+                               f"environment says {rank}/{W}")
+    return rank, local_rank, W
+
+
+def shutdown() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------- packing
+def _pack(feat: torch.Tensor, ids_a: Optional[torch.Tensor], ids_b: Optional[torch.Tensor], out: torch.Tensor) -> None:
+    """out[B, D (+4)] = feat | ids_a (int64 as 2 floats) | ids_b.  Device tensors take the HIP pack kernel."""
+    B, D = feat.shape
+    if feat.is_cuda:
+        from . import ops
+        ops.pack_rows(feat, ids_a, ids_b, out)
+        return
+    out[:, :D] = feat
+    if ids_a is not None:
+        out[:, D:D + 2].view(torch.int64).copy_(ids_a.view(B, 1))
+        out[:, D + 2:D + 4].view(torch.int64).copy_(ids_b.view(B, 1))
+
+
+def _ids_view(buf: torch.Tensor, D: int, which: int) -> torch.Tensor:
+    """int64 [G] tile ids out of the packed [G, D+4] fp32 gather buffer (no copy: strided int64 view)."""
+    G, cols = buf.shape
+    flat = buf.view(-1).view(torch.int64)          # cols is even (D is a multiple of 2, +4)
+    return flat.as_strided((G,), (cols // 2,), (D // 2 + which))
+
+
 def gather_packed(image_features: torch.Tensor, text_features: torch.Tensor,
                   image_tile_ids: Optional[torch.Tensor] = None, text_tile_ids: Optional[torch.Tensor] = None):
     """Rank-major concatenation of every rank's rows: returns (all_image, all_text, all_image_ids, all_text_ids).
-    Equal local batch on every rank is assumed, as by the reference (loss.py:96, losses.py:94)."""
+    Equal local batch on every rank is assumed, as by the reference (loss.py:96, losses.py:94).  Synchronous form:
+    ONE collective on the caller's stream."""
     if not is_dist():
         return image_features, text_features, image_tile_ids, text_tile_ids
     _, W = world()
@@ -53,6 +137,89 @@ def gather_packed(image_features: torch.Tensor, text_features: torch.Tensor,
         ids_t = out[:, 2 * D + 2:2 * D + 4].contiguous().view(torch.int64).view(-1)
         return all_i, all_t, ids_i, ids_t
     return all_i, all_t, None, None
+
+
+class FeatureGather:
+    """Overlapped global-batch formation (north-star: "RCCL all-gather ... overlapped with the final encoder block on
+    a side HIP stream").
+
+    Per step:  ``begin(ids_i, ids_t)`` -> ``put("text", f_t)`` as soon as the second tower has produced its features
+    (its rows + both id vectors are packed and all-gathered on the communication stream while the vision tower runs)
+    -> ``put("image", f_i)`` after the vision tower -> ``take("text")`` / ``take("image")`` make the *current* stream
+    wait for the matching gather (an event wait, never the host) and return the gathered tensors.
+
+    The communication stream owns persistent send / receive buffers, so nothing allocated on the compute stream is
+    ever touched by another stream (no caching-allocator hazards), and the result is bit-identical to
+    ``gather_packed``: an all-gather moves bytes."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.cuda = device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=device, priority=-1) if self.cuda else None
+        self._send, self._recv, self._done, self._src = {}, {}, {}, {}
+        self._ids = (None, None)
+        self.launched = 0          # number of collectives issued (tests)
+
+    def begin(self, ids_i: Optional[torch.Tensor], ids_t: Optional[torch.Tensor]) -> None:
+        self._ids = (ids_i, ids_t)
+        self._done.clear()
+        self._src.clear()
+
+    def _buf(self, table, key, shape):
+        t = table.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            table[key] = t
+        return t
+
+    def put(self, which: str, feat: torch.Tensor) -> None:
+        if not is_dist():
+            return
+        _, W = world()
+        B, D = feat.shape
+        ids_i, ids_t = self._ids if which == "text" else (None, None)
+        cols = D + (4 if ids_i is not None else 0)
+        send = self._buf(self._send, which, (B, cols))
+        recv = self._buf(self._recv, which, (W * B, cols))
+        self._src[which] = (feat.data_ptr(), D, ids_i is not None)
+        if not self.cuda:
+            _pack(feat, ids_i, ids_t, send)
+            dist.all_gather_into_tensor(recv, send)
+            self._done[which] = None
+            self.launched += 1
+            return
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.stream.wait_event(ready)               # the features are final on the compute stream
+        with torch.cuda.stream(self.stream):
+            _pack(feat, ids_i, ids_t, send)
+            work = dist.all_gather_into_tensor(recv, send, async_op=True)
+            work.wait()                             # nccl: the communication stream waits for RCCL's stream (no host block)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self._done[which] = done
+        self.launched += 1
+
+    def has(self, which: str, feat: torch.Tensor) -> bool:
+        src = self._src.get(which)
+        return src is not None and src[0] == feat.data_ptr() and which in self._done
+
+    def with_ids(self, which: str) -> bool:
+        src = self._src.get(which)
+        return src is not None and src[2]
+
+    def take(self, which: str):
+        """-> (all_features [G, D] (row stride D or D+4), all_ids_i, all_ids_t)  (ids only for "text")."""
+        done = self._done[which]
+        if done is not None:
+            torch.cuda.current_stream(self.device).wait_event(done)
+        _, D, with_ids = self._src[which]
+        recv = self._recv[which]
+        feats = recv[:, :D]
+        if with_ids:
+            return feats, _ids_view(recv, D, 0), _ids_view(recv, D, 1)
+        return feats, None, None
 
 
 def reduce_scatter_sum(full: torch.Tensor) -> torch.Tensor:

@@ -3,14 +3,24 @@ forward AND backward in one pass (the loss is always differentiated during train
 features are produced while the similarity matrix is still hot).
 
 Reference semantics: open_clip ClipLoss (src/open_clip/loss.py:91-155, local_loss layout) and SpatialLoss
-(src/models/components/losses.py:44-124).  Nothing here synchronises with the host."""
+(src/models/components/losses.py:44-124).  Nothing here synchronises with the host.
+
+The six matrix products (two similarity matrices, four gradient products) are exact-fp32 MFMA GEMMs
+(``sc_sgemm_f32_grouped``): one launch for the forward pair, one for the backward four."""
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Callable, Dict, Optional
 
 import torch
 
 from . import ops
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, D] with unit inner stride (the row stride may exceed D: gathered features sit in the packed
+    receive buffer of the all-gather and are read in place)."""
+    t = t.float()
+    return t if t.stride(1) == 1 else t.contiguous()
 
 
 def contrastive_forward_backward(
@@ -20,25 +30,39 @@ def contrastive_forward_backward(
         all_image_tile_ids: Optional[torch.Tensor] = None, all_text_tile_ids: Optional[torch.Tensor] = None,
         neighbor_tile_ids: Optional[torch.Tensor] = None, neighbor_alphas: Optional[torch.Tensor] = None,
         cap_logit_scale: Optional[float] = None, temp_reg_weight: float = 0.0, neighbor_alpha_scale: float = 1.0,
-        logit_bias: Optional[torch.Tensor] = None, recall_hits: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-    """Returns loss (0-d), d_image/d_text [B,D] (direct terms), d_all_image/d_all_text [G,D] (this rank's
+        logit_bias: Optional[torch.Tensor] = None, recall_hits: Optional[torch.Tensor] = None,
+        recall_rows: Optional[tuple] = None,
+        late_all_image: Optional[Callable[[], torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """Returns loss (0-d), d_image/d_text [B,D] (direct terms), d_all [G,2D] = d_all_image | d_all_text (this rank's
     contribution to EVERY rank's features = the operand of the reduce-scatter that is the autograd of
-    torch.distributed.nn.all_gather, loss.py:50-52), d_scale, d_bias, recall_hits (R@1/5/10 hit counters)."""
-    f_i = image_features.contiguous().float()
-    f_t = text_features.contiguous().float()
-    a_i = f_i if all_image is None else all_image.contiguous().float()
-    a_t = f_t if all_text is None else all_text.contiguous().float()
+    torch.distributed.nn.all_gather, loss.py:50-52), d_scale, d_bias, recall_hits (R@1/5/10 hit counters).
+
+    ``late_all_image``: callable returning ``all_image`` -- invoked only after the first similarity GEMM
+    (image . all_text^T, which does not need it) has been enqueued, so a still-running all-gather of the image
+    features overlaps with that GEMM.  ``recall_rows = (row0, n)``: the rows of z[0] whose diagonal block feeds R@k
+    (default: all B rows, diagonal at column rank*B)."""
+    f_i = _rows(image_features)
+    f_t = _rows(text_features)
+    a_t = f_t if all_text is None else _rows(all_text)
     dev = f_i.device
     B, D = f_i.shape
-    G = a_i.shape[0]
-    if a_t.shape[0] != G or f_t.shape != f_i.shape:
+    G = a_t.shape[0]
+    if f_t.shape != f_i.shape:
         raise ValueError("feature shapes disagree")
     if (rank + 1) * B > G:
         raise ValueError(f"rank {rank} with local batch {B} does not fit global batch {G}")
     scale = logit_scale.detach().reshape(1).float()
     z = torch.empty((2, B, G), dtype=torch.float32, device=dev)
-    ops.sgemm(f_i, D, 1, a_t, D, 1, z[0], G, B, G, D)
-    ops.sgemm(f_t, D, 1, a_i, D, 1, z[1], G, B, G, D)
+    p_it = (f_i, f_i.stride(0), 1, a_t, a_t.stride(0), 1, z[0], G, B, G, D)
+    if late_all_image is not None:
+        ops.sgemm_grouped([p_it])
+        a_i = _rows(late_all_image())
+        ops.sgemm_grouped([(f_t, f_t.stride(0), 1, a_i, a_i.stride(0), 1, z[1], G, B, G, D)])
+    else:
+        a_i = f_i if all_image is None else _rows(all_image)
+        ops.sgemm_grouped([p_it, (f_t, f_t.stride(0), 1, a_i, a_i.stride(0), 1, z[1], G, B, G, D)])
+    if a_i.shape[0] != G:
+        raise ValueError("gathered image / text batches disagree")
 
     if mode == "clip":
         nlab = 1
@@ -68,7 +92,11 @@ def contrastive_forward_backward(
     ops.contrastive_loss_fwd(z, B, G, scale, cap, bias, lab_col, lab_w, nlab, w, rowstats, loss_out)
     if recall_hits is None:
         recall_hits = torch.zeros(3, dtype=torch.int32, device=dev)
-    ops.recall_hits(z[0], G, B, rank * B, recall_hits)
+    if recall_rows is None:
+        ops.recall_hits(z[0], G, B, rank * B, recall_hits)
+    else:           # a window of a [G,G] matrix: rows row0.. whose diagonal sits at the same column offset
+        row0, nrow = recall_rows
+        ops.recall_hits(z[0][row0:], G, nrow, row0, recall_hits)
     rowgrad = torch.empty((2 * B, 2), dtype=torch.float32, device=dev)
     d_scale = torch.empty(1, dtype=torch.float32, device=dev)
     d_bias = torch.empty(1, dtype=torch.float32, device=dev)
@@ -76,12 +104,13 @@ def contrastive_forward_backward(
                              d_scale, d_bias)
     d_image = torch.empty((B, D), dtype=torch.float32, device=dev)
     d_text = torch.empty((B, D), dtype=torch.float32, device=dev)
-    d_all_image = torch.empty((G, D), dtype=torch.float32, device=dev)
-    d_all_text = torch.empty((G, D), dtype=torch.float32, device=dev)
-    ops.sgemm(z[0], G, 1, a_t, 1, D, d_image, D, B, D, G)         # dz_it . all_text
-    ops.sgemm(z[0], 1, G, f_i, 1, D, d_all_text, D, G, D, B)      # dz_it^T . image
-    ops.sgemm(z[1], G, 1, a_i, 1, D, d_text, D, B, D, G)          # dz_ti . all_image
-    ops.sgemm(z[1], 1, G, f_t, 1, D, d_all_image, D, G, D, B)     # dz_ti^T . text
-    return {"loss": loss_out[0], "gap": loss_out[1], "d_image": d_image, "d_text": d_text,
-            "d_all_image": d_all_image, "d_all_text": d_all_text, "d_scale": d_scale[0], "d_bias": d_bias[0],
+    d_all = torch.empty((G, 2 * D), dtype=torch.float32, device=dev)       # d_all_image | d_all_text
+    ops.sgemm_grouped([
+        (z[0], G, 1, a_t, 1, a_t.stride(0), d_image, D, B, D, G),            # dz_it . all_text        (K = G: first)
+        (z[1], G, 1, a_i, 1, a_i.stride(0), d_text, D, B, D, G),             # dz_ti . all_image
+        (z[0], 1, G, f_i, 1, f_i.stride(0), d_all[:, D:], 2 * D, G, D, B),   # dz_it^T . image  -> d all_text
+        (z[1], 1, G, f_t, 1, f_t.stride(0), d_all[:, :D], 2 * D, G, D, B),   # dz_ti^T . text   -> d all_image
+    ])
+    return {"loss": loss_out[0], "gap": loss_out[1], "d_image": d_image, "d_text": d_text, "d_all": d_all,
+            "d_all_image": d_all[:, :D], "d_all_text": d_all[:, D:], "d_scale": d_scale[0], "d_bias": d_bias[0],
             "recall_hits": recall_hits}

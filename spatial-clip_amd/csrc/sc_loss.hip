@@ -3,77 +3,16 @@
 //   reference: src/open_clip/loss.py:91-155 (ClipLoss, local_loss layout)
 //              src/models/components/losses.py:44-124 (SpatialLoss)        closed forms: SURVEY.md Appendix A
 // Pipeline (all fp32, tiny next to the towers):
-//   sc_sgemm_f32         z = f . all_f^T                      (cosine similarities, both directions)
+//   sc_sgemm_f32_grouped z = f . all_f^T  (cosine similarities, both directions; exact-fp32 MFMA, sc_head_gemm.hip)
 //   sc_neighbor_join     tile-id join -> sparse soft labels (<= K+1 (col, weight) pairs per row)
 //   sc_loss_rows_fwd     per row: logsumexp, E_p[z], sum q*logit, sum q*z
 //   sc_loss_finalize     loss = 0.5*(CE_i + CE_t) + w*gap^2 ; gap
 //   sc_loss_rows_bwd     dz (in place over z), d logit_scale, d logit_bias
-//   sc_sgemm_f32         d f_local = dz . all_f ,  d all_f = dz^T . f_local  (the latter is reduce-scattered)
+//   sc_sgemm_f32_grouped d f_local = dz . all_f ,  d all_f = dz^T . f_local  (the latter is reduce-scattered)
 #include "sc_common.h"
 #include "sc_kernels.h"
 
 namespace {
-
-// ---------------------------------------------------------------- small strided fp32 GEMM (64x64x16 tiles)
-// C[m][n] (+)= sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk]
-template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, long long sam, long long sak,
-                                                    const float* __restrict__ B, long long sbn, long long sbk,
-                                                    float* __restrict__ C, long long ldc, int M, int N, int K,
-                                                    int accumulate) {
-    __shared__ float As[16][68];
-    __shared__ float Bs[16][68];
-    const int t = threadIdx.x;
-    const int tx = t & 15, ty = t >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int idx = p * 256 + t;
-            {
-                const int kk = A_KCONTIG ? (idx & 15) : (idx >> 6);
-                const int mm = A_KCONTIG ? (idx >> 4) : (idx & 63);
-                const int gm = m0 + mm, gk = k0 + kk;
-                As[kk][mm] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
-            }
-            {
-                const int kk = B_KCONTIG ? (idx & 15) : (idx >> 6);
-                const int nn = B_KCONTIG ? (idx >> 4) : (idx & 63);
-                const int gn = n0 + nn, gk = k0 + kk;
-                Bs[kk][nn] = (gn < N && gk < K) ? B[gn * sbn + gk * sbk] : 0.f;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[kk][ty * 4]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[kk][tx * 4]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + ty * 4 + i;
-        if (gm >= M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gn = n0 + tx * 4 + j;
-            if (gn < N) {
-                float* c = C + gm * ldc + gn;
-                *c = accumulate ? *c + acc[i][j] : acc[i][j];
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------- tile-id join -> sparse labels
 // One block per local row i.  Entry 0 = the anchor column (rank*B + i, weight 1), entries 1..K = neighbours.
@@ -350,20 +289,6 @@ __global__ __launch_bounds__(256) void pcc_rows_kernel(const float* __restrict__
 }
 
 }  // namespace
-
-extern "C" int sc_sgemm_f32(const float* A, long long sam, long long sak, const float* B, long long sbn, long long sbk,
-                            float* C, long long ldc, int M, int N, int K, int accumulate, void* stream) {
-    SC_CHECK(M > 0 && N > 0 && K > 0, "sc_sgemm_f32: empty problem");
-    dim3 grid((N + 63) / 64, (M + 63) / 64);
-    hipStream_t st = (hipStream_t)stream;
-    const bool ak = (sak == 1), bk = (sbk == 1);
-    if (ak && bk) sgemm_kernel<true, true><<<grid, 256, 0, st>>>(A, sam, sak, B, sbn, sbk, C, ldc, M, N, K, accumulate);
-    else if (ak) sgemm_kernel<true, false><<<grid, 256, 0, st>>>(A, sam, sak, B, sbn, sbk, C, ldc, M, N, K, accumulate);
-    else if (bk) sgemm_kernel<false, true><<<grid, 256, 0, st>>>(A, sam, sak, B, sbn, sbk, C, ldc, M, N, K, accumulate);
-    else sgemm_kernel<false, false><<<grid, 256, 0, st>>>(A, sam, sak, B, sbn, sbk, C, ldc, M, N, K, accumulate);
-    SC_LAUNCH_CHECK();
-    return 0;
-}
 
 extern "C" int sc_neighbor_join(const long long* all_image_tile_ids, const long long* all_text_tile_ids,
                                 const long long* neighbor_tile_ids, const float* neighbor_alphas, int B, int G, int K,

@@ -22,28 +22,53 @@ class _ContrastiveFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image_features, text_features, logit_scale, owner, kw):
         rank, W = comm.world()
-        if owner.world_size_override is not None:
-            rank, W = owner.rank_override, owner.world_size_override
+        dist_on = comm.is_dist()
         ids_i, ids_t = kw.get("image_tile_ids"), kw.get("text_tile_ids")
         img = image_features.detach().contiguous().float()
         txt = text_features.detach().contiguous().float()
-        all_i, all_t, all_ids_i, all_ids_t = comm.gather_packed(img, txt, ids_i, ids_t)
-        res = contrastive_forward_backward(
-            img, txt, logit_scale.detach(), mode=owner.mode, all_image=all_i, all_text=all_t,
-            rank=rank if comm.is_dist() else 0,
-            image_tile_ids=ids_i, text_tile_ids=ids_t, all_image_tile_ids=all_ids_i, all_text_tile_ids=all_ids_t,
-            neighbor_tile_ids=kw.get("neighbor_tile_ids"), neighbor_alphas=kw.get("neighbor_alphas"),
-            cap_logit_scale=owner.cap_logit_scale, temp_reg_weight=owner.temp_reg_weight,
-            neighbor_alpha_scale=owner.neighbor_alpha_scale, logit_bias=kw.get("logit_bias"),
-            recall_hits=owner.recall_hits)
-        D = img.shape[1]
-        if owner.gather_with_grad or not comm.is_dist():
-            # autograd of torch.distributed.nn.all_gather (loss.py:50-52): SUM over ranks, keep own rows
-            both = comm.reduce_scatter_sum(torch.cat([res["d_all_image"], res["d_all_text"]], dim=1))
-            d_img = res["d_image"] + both[:, :D]
-            d_txt = res["d_text"] + both[:, D:]
+        B, D = img.shape
+        all_i = all_t = all_ids_i = all_ids_t = late = None
+        fg = owner.prefetched
+        need_ids = owner.mode == "spatial"
+        if dist_on and fg is not None and fg.has("text", txt) and fg.has("image", img) \
+                and (not need_ids or fg.with_ids("text")):
+            # the gathers were launched from inside the net's forward on the communication stream; the image
+            # features are only waited for after the first similarity GEMM has been enqueued
+            all_t, all_ids_i, all_ids_t = fg.take("text")
+            late = lambda: fg.take("image")[0]
+        elif dist_on:
+            all_i, all_t, all_ids_i, all_ids_t = comm.gather_packed(img, txt, ids_i if need_ids else None,
+                                                                     ids_t if need_ids else None)
+        common = dict(mode=owner.mode, image_tile_ids=ids_i, text_tile_ids=ids_t, all_image_tile_ids=all_ids_i,
+                      all_text_tile_ids=all_ids_t, neighbor_tile_ids=kw.get("neighbor_tile_ids"),
+                      neighbor_alphas=kw.get("neighbor_alphas"), cap_logit_scale=owner.cap_logit_scale,
+                      temp_reg_weight=owner.temp_reg_weight, neighbor_alpha_scale=owner.neighbor_alpha_scale,
+                      logit_bias=kw.get("logit_bias"), recall_hits=owner.recall_hits)
+        if dist_on and owner.mode == "clip" and not owner.local_loss:
+            # loss.py:119-121: every rank forms the full [G,G] logits of the global batch (labels arange(G))
+            if late is not None:
+                all_i = late()
+            res = contrastive_forward_backward(all_i, all_t, logit_scale.detach(), rank=0,
+                                               recall_rows=(rank * B, B), **common)
+            tot = torch.cat([res["d_image"] + res["d_all_image"], res["d_text"] + res["d_all_text"]], dim=1)
+            if owner.gather_with_grad:
+                both = comm.reduce_scatter_sum(tot)                 # every rank contributes its (identical) full-loss term
+            else:
+                both = tot[rank * B:(rank + 1) * B]                  # loss.py:58-61: only the spliced local shard has grad
+            d_img, d_txt = both[:, :D].contiguous(), both[:, D:].contiguous()
         else:
-            d_img, d_txt = res["d_image"], res["d_text"]       # loss.py:54-63 with local_loss: remote shards detached
+            res = contrastive_forward_backward(img, txt, logit_scale.detach(), all_image=all_i, all_text=all_t,
+                                               rank=rank if dist_on else 0, late_all_image=late, **common)
+            if dist_on and owner.gather_with_grad:
+                # autograd of torch.distributed.nn.all_gather (loss.py:50-52): SUM over ranks, keep own rows
+                both = comm.reduce_scatter_sum(res["d_all"])
+                d_img = res["d_image"] + both[:, :D]
+                d_txt = res["d_text"] + both[:, D:]
+            elif dist_on:
+                d_img, d_txt = res["d_image"], res["d_text"]     # loss.py:54-63 with local_loss: remote shards detached
+            else:
+                d_img = res["d_image"] + res["d_all_image"]
+                d_txt = res["d_text"] + res["d_all_text"]
         ctx.save_for_backward(d_img, d_txt, res["d_scale"])
         owner.last = res
         return res["loss"].clone()
@@ -66,10 +91,11 @@ class _LossBase(torch.nn.Module):
         self.local_loss = local_loss
         self.gather_with_grad = gather_with_grad
         self.use_horovod = use_horovod
-        # explicit rank/world_size only matter for single-process emulation in tests; a live process group wins
-        self.rank_override, self.world_size_override = (rank, world_size) if world_size > 1 and not comm.is_dist() \
-            else (0, None)
+        # rank / world_size ctor kwargs are accepted for signature parity (loss.py:71-78) but the LIVE process group
+        # decides at call time: under Lightning the reference constructs its losses before the group exists and
+        # therefore never gathers ("distributed quirk"); the intended behaviour is built here
         self.recall_hits: Optional[torch.Tensor] = None
+        self.prefetched: Optional[comm.FeatureGather] = None      # set by the module: gathers launched inside the net
         self.last: Dict[str, torch.Tensor] = {}
 
     @property
@@ -82,10 +108,11 @@ class _LossBase(torch.nn.Module):
 
 
 class ClipLoss(_LossBase):
-    """``ClipLoss(local_loss, gather_with_grad, cache_labels, rank, world_size, use_horovod)``; the global-batch
-    layout is always the memory-lean ``local_loss=True`` one ([B,G] per rank) -- for ``local_loss=False`` the
-    reference's full [G,G] loss equals the mean over ranks of these per-rank losses, which is what data-parallel
-    gradient averaging optimises anyway."""
+    """``ClipLoss(local_loss, gather_with_grad, cache_labels, rank, world_size, use_horovod)``.
+    ``local_loss=True``: each rank scores its B rows against the global batch ([B,G], loss.py:116-118);
+    ``local_loss=False``: each rank forms the full [G,G] logits (loss.py:119-121) -- W times the work for the same
+    optimisation objective, kept for parity with the constructor default.  ``gather_with_grad=False`` detaches the
+    remote shards (loss.py:54-63)."""
     mode = "clip"
 
     def __init__(self, local_loss: bool = False, gather_with_grad: bool = False, cache_labels: bool = False,

@@ -12,13 +12,45 @@ from typing import Any, Callable, Dict, Optional
 
 import torch
 
-from . import ops
+from . import comm, ops
 from .metrics import ContrastiveMetrics, ZeroShotGeneExpressionMetric
 from .net import SpatialClipNet
 
 
 class _HParams(dict):
     __getattr__ = dict.get
+
+
+class StepOutput(dict):
+    """``model_step`` result with the reference's keys (``loss``, ``logits``, ``image_features``;
+    spatial_clip_module.py:66-70).  ``logits`` -- the local [B,B] ``image_features @ text_features.T * logit_scale``
+    the reference computes for its metrics -- is materialised on first access: R@k already rides on the loss
+    kernels' similarity matrix here, so the training step itself never needs it."""
+
+    _LAZY = "logits"
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        dict.__setitem__(self, self._LAZY, None)
+
+    def _materialise(self):
+        v = dict.__getitem__(self, self._LAZY)
+        if v is None:
+            v = SpatialClipLitModule.local_logits(self)
+            dict.__setitem__(self, self._LAZY, v)
+        return v
+
+    def __getitem__(self, k):
+        return self._materialise() if k == self._LAZY else dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
 
 
 class SpatialClipLitModule(torch.nn.Module):
@@ -38,6 +70,7 @@ class SpatialClipLitModule(torch.nn.Module):
         self.zero_shot_metric = ZeroShotGeneExpressionMetric(global_hvg_path=global_hvg_path) if global_hvg_path else None
         self.gene_bank_embeddings = None
         self.trainer = None
+        self._feature_gather = None
         self.logged: Dict[str, Any] = {}
         # spatial_clip_module.py:44 -- cache the kwarg names the loss accepts, once
         self._loss_fn_arg_names = set(inspect.signature(self.loss_fn.forward).parameters.keys())
@@ -56,7 +89,20 @@ class SpatialClipLitModule(torch.nn.Module):
         return self.net(images, texts)
 
     def model_step(self, batch: Dict[str, Any], metrics: Optional[ContrastiveMetrics] = None) -> Dict[str, torch.Tensor]:
+        # W > 1: let the net launch the feature all-gathers from inside its forward (text side under the vision tower,
+        # image side under the first similarity GEMM); the loss picks the gathered tensors up by identity
+        fg = None
+        if comm.is_dist() and hasattr(self.loss_fn, "prefetched") and os.environ.get("SC_GATHER_OVERLAP", "1") != "0":
+            fg = self._feature_gather
+            if fg is None:
+                fg = self._feature_gather = comm.FeatureGather(self.device)
+            want_ids = "image_tile_ids" in self._loss_fn_arg_names
+            fg.begin(batch.get("image_tile_ids") if want_ids else None, batch.get("text_tile_ids") if want_ids else None)
+        self.net.feature_gather = fg
+        if hasattr(self.loss_fn, "prefetched"):
+            self.loss_fn.prefetched = fg
         features = self.forward(batch["images"], batch["texts"])
+        self.net.feature_gather = None
         available_data = {**features, **batch}
         loss_input = {k: v for k, v in available_data.items() if k in self._loss_fn_arg_names}
         fused_hits = metrics is not None and hasattr(self.loss_fn, "recall_hits")
@@ -67,19 +113,18 @@ class SpatialClipLitModule(torch.nn.Module):
         if fused_hits:
             metrics.add_hits(features["image_features"].shape[0])
             self.loss_fn.recall_hits = None
-        output = {"loss": loss_dict["contrastive_loss"], "image_features": features["image_features"],
-                  "text_features": features["text_features"], "logit_scale": features["logit_scale"]}
-        return output
+        return StepOutput({"loss": loss_dict["contrastive_loss"], "image_features": features["image_features"],
+                           "text_features": features["text_features"], "logit_scale": features["logit_scale"]})
 
     @staticmethod
     def local_logits(output: Dict[str, torch.Tensor]) -> torch.Tensor:
         """``image_features @ text_features.T * logit_scale`` (spatial_clip_module.py:68), on demand."""
-        f_i = output["image_features"].detach().contiguous()
-        f_t = output["text_features"].detach().contiguous()
+        f_i = dict.__getitem__(output, "image_features").detach().contiguous()
+        f_t = dict.__getitem__(output, "text_features").detach().contiguous()
         B, D = f_i.shape
         z = torch.empty((B, B), dtype=torch.float32, device=f_i.device)
         ops.sgemm(f_i, D, 1, f_t, D, 1, z, B, B, B, D)
-        return z * output["logit_scale"].detach()
+        return z * dict.__getitem__(output, "logit_scale").detach()
 
     def training_step(self, batch: Dict[str, Any], batch_idx: int) -> torch.Tensor:
         output = self.model_step(batch, self.train_metrics)

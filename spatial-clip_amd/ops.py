@@ -2,6 +2,7 @@
 Every function enqueues on the current HIP stream and never synchronises."""
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
@@ -246,6 +247,51 @@ def sgemm(a, sam, sak, b, sbn, sbk, c, ldc, M, N, K, accumulate=False):
     check(_lib.lib().sc_sgemm_f32(a.data_ptr(), sam, sak, b.data_ptr(), sbn, sbk, c.data_ptr(), ldc, M, N, K,
                                   int(accumulate), _stream()), "sc_sgemm_f32")
     return c
+
+
+class _SgemmDesc(ctypes.Structure):
+    """``sc_sgemm_desc`` of include/spatial_clip_hip.h (host-side problem descriptor)."""
+    _fields_ = [("A", ctypes.c_void_p), ("sam", ctypes.c_longlong), ("sak", ctypes.c_longlong),
+                ("B", ctypes.c_void_p), ("sbn", ctypes.c_longlong), ("sbk", ctypes.c_longlong),
+                ("C", ctypes.c_void_p), ("ldc", ctypes.c_longlong),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("accumulate", ctypes.c_int)]
+
+
+SGEMM_MAX_GROUP = 6
+
+
+def sgemm_grouped(problems) -> None:
+    """Several independent fp32 GEMMs in one launch.  ``problems``: iterable of
+    (a, sam, sak, b, sbn, sbk, c, ldc, M, N, K[, accumulate]) exactly as for :func:`sgemm`."""
+    problems = list(problems)
+    if not 1 <= len(problems) <= SGEMM_MAX_GROUP:
+        raise ValueError(f"sgemm_grouped: 1..{SGEMM_MAX_GROUP} problems, got {len(problems)}")
+    arr = (_SgemmDesc * len(problems))()
+    for d, p in zip(arr, problems):
+        a, sam, sak, b, sbn, sbk, c, ldc, M, N, K = p[:11]
+        for t_, n in ((a, "a"), (b, "b"), (c, "c")):
+            if not t_.is_cuda or t_.dtype != torch.float32:
+                raise TypeError(f"sgemm_grouped: {n} must be a device fp32 tensor")
+        d.A, d.sam, d.sak = a.data_ptr(), sam, sak
+        d.B, d.sbn, d.sbk = b.data_ptr(), sbn, sbk
+        d.C, d.ldc = c.data_ptr(), ldc
+        d.M, d.N, d.K, d.accumulate = M, N, K, int(p[11]) if len(p) > 11 else 0
+    check(_lib.lib().sc_sgemm_f32_grouped(ctypes.cast(arr, ctypes.c_void_p), len(problems), _stream()),
+          "sc_sgemm_f32_grouped")
+
+
+def pack_rows(feat: torch.Tensor, ids_a: Optional[torch.Tensor], ids_b: Optional[torch.Tensor],
+              out: torch.Tensor) -> torch.Tensor:
+    """out[B, D(+4)] = feat | ids_a | ids_b (int64 through two float slots each): all-gather send buffer."""
+    _req(feat, torch.float32, "feat"); _req(out, torch.float32, "out")
+    if ids_a is not None:
+        _req(ids_a, torch.int64, "ids_a"); _req(ids_b, torch.int64, "ids_b")
+        if not (ids_a.is_contiguous() and ids_b.is_contiguous()):
+            raise ValueError("pack_rows: id vectors must be contiguous")
+    B, D = feat.shape
+    check(_lib.lib().sc_pack_rows(feat.data_ptr(), feat.stride(0), _ptr(ids_a), _ptr(ids_b), out.data_ptr(),
+                                  out.stride(0), B, D, _stream()), "sc_pack_rows")
+    return out
 
 
 def neighbor_join(all_img_ids, all_txt_ids, nbr_ids, nbr_alpha, B, G, K, rank, alpha_scale, lab_col, lab_w):

@@ -365,6 +365,10 @@ class VisionTower:
         self.f = f
         return f
 
+    def raw_features(self) -> torch.Tensor:
+        """Projected features of the last forward before F.normalize (encode_image(normalize=False))."""
+        return self.bufs.get("f_raw", (self.B, self.D), F32)
+
     def backward(self, d_f: torch.Tensor, on_bucket: Optional[Callable[[List[str]], None]] = None) -> None:
         s, d, D, L, B = self.s, self.d, self.D, self.L, self.B
         M, Mp = B * L, B * (L - 1)
@@ -454,6 +458,9 @@ class GeneTower:
         self.f = f
         return f
 
+    def raw_features(self) -> torch.Tensor:
+        return self.bufs.get("f_raw", (self.B, self.D), F32)
+
     def backward(self, d_f: torch.Tensor, on_bucket: Optional[Callable[[List[str]], None]] = None) -> None:
         s, g, D, B = self.s, self.g, self.D, self.B
         bf = self.bufs
@@ -516,6 +523,9 @@ class TextTower:
         ops.l2norm_fwd(f_raw, f, None, bf.get("inv", (B,), F32), B, D)
         self.f = f
         return f
+
+    def raw_features(self) -> torch.Tensor:
+        return self.bufs.get("f_raw", (self.B, self.D), F32)
 
     def backward(self, d_f: torch.Tensor, on_bucket: Optional[Callable[[List[str]], None]] = None) -> None:
         s, d, D, L, B = self.s, self.d, self.D, self.L, self.B

@@ -2,6 +2,8 @@
 datamodule / model / trainer -> handshake preprocess_fn + tokenizer -> fit -> test.
 
     python -m spatial_clip_amd.train experiment=smoke_shards trainer.max_epochs=1 [--config-dir /path/to/configs]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           -m spatial_clip_amd.train experiment=vitb16_gene_8gpu          (one process per GPU, RCCL over xGMI)
 """
 from __future__ import annotations
 
@@ -10,10 +12,17 @@ from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 
-from . import hydra_lite
+from . import comm, hydra_lite
+from .trainer import _requested_world
 
 
 def train(cfg) -> Tuple[Dict[str, Any], Dict[str, Any]]:
+    # One process per GPU (reference: Lightning's DDP strategy re-launches src/train.py per device; here the launcher is
+    # torch.distributed.run).  Bind to cuda:LOCAL_RANK and join the RCCL group BEFORE the model allocates anything;
+    # a trainer config that asks for more ranks than the launcher started raises (no silent single-GPU "DP8").
+    tcfg = cfg.get("trainer") or {}
+    comm.init_from_env(expect_world=_requested_world(tcfg.get("devices", "auto"), tcfg.get("num_nodes", 1))
+                       if comm.env_world()[2] > 1 else None)
     if cfg.get("seed") is not None:
         torch.manual_seed(int(cfg.seed))                       # L.seed_everything (src/train.py:56-57)
     datamodule = hydra_lite.instantiate(cfg.data)
@@ -21,6 +30,8 @@ def train(cfg) -> Tuple[Dict[str, Any], Dict[str, Any]]:
     model.hparams["optimized_metric"] = cfg.get("optimized_metric", "val/loss")
     datamodule.preprocess_fn = model.net.preprocess_train      # handshake, src/train.py:70-73
     datamodule.tokenizer = model.net.tokenizer
+    if "save_ckpt" in cfg and isinstance(cfg.get("trainer"), dict):
+        cfg.trainer["enable_checkpointing"] = bool(cfg.save_ckpt)          # src/train.py:92-99
     trainer = hydra_lite.instantiate(cfg.trainer)
     objects = {"cfg": cfg, "datamodule": datamodule, "model": model, "trainer": trainer}
     metrics: Dict[str, Any] = {}
@@ -28,7 +39,11 @@ def train(cfg) -> Tuple[Dict[str, Any], Dict[str, Any]]:
         trainer.fit(model=model, datamodule=datamodule, ckpt_path=cfg.get("ckpt_path"))
         metrics.update(getattr(trainer, "callback_metrics", {}))
     if cfg.get("test", False):
-        out = trainer.test(model=model, datamodule=datamodule)
+        ckpt_path = None                                         # src/train.py:126-133: best checkpoint if one exists
+        if trainer.checkpoint_callback is not None and trainer.checkpoint_callback.best_model_path:
+            ckpt_path = trainer.checkpoint_callback.best_model_path
+        datamodule.preprocess_fn = model.net.preprocess_val     # test-time handshake, src/train.py:136-138
+        out = trainer.test(model=model, datamodule=datamodule, ckpt_path=ckpt_path)
         if out:
             metrics.update(out[0])
     return metrics, objects
@@ -43,7 +58,9 @@ def main(argv: Optional[List[str]] = None) -> Dict[str, Any]:
         del argv[i:i + 2]
     cfg = hydra_lite.compose("train.yaml", argv, config_dir=config_dir)
     metrics, _ = train(cfg)
-    print({k: (round(v, 5) if isinstance(v, float) else v) for k, v in metrics.items()})
+    if comm.world()[0] == 0:
+        print({k: (round(v, 5) if isinstance(v, float) else v) for k, v in metrics.items()})
+    comm.shutdown()
     return metrics
 
 

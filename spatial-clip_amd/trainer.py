@@ -1,12 +1,21 @@
 """Minimal Lightning-free trainer honouring the ``lightning.pytorch.Trainer`` kwargs the reference's configs use
 (configs/trainer/*.yaml): max_epochs / max_steps, precision ("bf16-mixed" is what the kernels implement),
-gradient_clip_val, limit_*_batches, fast_dev_run, devices / strategy (one process per GPU launched by torchrun;
-gradient reduction is this package's bucketed RCCL all-reduce, not a DDPStrategy).  Loop semantics per step
-(SURVEY.md 3.2): training_step -> loss.backward() -> grad all-reduce (mean) -> clip_grad_norm_ -> AdamW.step ->
-scheduler.step()."""
+gradient_clip_val, limit_*_batches, fast_dev_run, devices / strategy / num_nodes, default_root_dir,
+enable_checkpointing.
+
+Multi-GPU (reference: ``strategy: ddp``, configs/trainer/ddp.yaml; Lightning re-launches the script per GPU): here
+the launcher is ``python -m torch.distributed.run --nproc-per-node N``; the Trainer joins the RCCL process group the
+launcher describes (``comm.init_from_env``), REFUSES to run when ``devices x num_nodes`` disagrees with the world
+the launcher started, and reduces gradients with this package's bucketed all-reduce (no DDPStrategy).
+
+Loop semantics per step: training_step -> loss.backward() -> grad all-reduce (mean) ->
+clip_grad_norm_ -> AdamW.step -> scheduler.step().  Checkpoints (reference: ModelCheckpoint monitor ``val/R@1``,
+``save_last``; configs/callbacks/default.yaml:8-14, gated by ``save_ckpt`` -> ``enable_checkpointing``,
+src/train.py:77-99) are written by rank 0 under ``default_root_dir/checkpoints``; ``fit(ckpt_path=...)`` resumes
+weights, optimiser moments, LR schedule and the step counter (src/train.py:119)."""
 from __future__ import annotations
 
-import math
+import os
 import time
 from typing import Any, Dict, Optional
 
@@ -19,25 +28,74 @@ def _to_device(batch: Dict[str, Any], device) -> Dict[str, Any]:
     return {k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
 
 
+def _requested_world(devices: Any, num_nodes: int) -> Optional[int]:
+    """Ranks the config asks for, or None when it leaves the choice to the launcher ("auto", -1)."""
+    if devices in ("auto", None, -1, "-1"):
+        return None
+    if isinstance(devices, (list, tuple)):
+        n = len(devices)
+    else:
+        n = int(devices)
+    return n * max(1, int(num_nodes))
+
+
+class CheckpointCallback:
+    """The slice of ``lightning.pytorch.callbacks.ModelCheckpoint`` that src/train.py reads back."""
+
+    def __init__(self, dirpath: str, monitor: str = "val/R@1", mode: str = "max"):
+        self.dirpath, self.monitor, self.mode = dirpath, monitor, mode
+        self.best_model_path = ""
+        self.last_model_path = ""
+        self.best_model_score: Optional[float] = None
+
+    def is_better(self, value: float) -> bool:
+        if self.best_model_score is None:
+            return True
+        return value > self.best_model_score if self.mode == "max" else value < self.best_model_score
+
+
 class Trainer:
     def __init__(self, max_epochs: Optional[int] = 1, min_epochs: int = 1, max_steps: int = -1, accelerator: str = "auto",
                  devices: Any = "auto", precision: str = "bf16-mixed", gradient_clip_val: Optional[float] = None,
                  check_val_every_n_epoch: int = 1, log_every_n_steps: int = 50, fast_dev_run: Any = False,
                  limit_train_batches: float = 1.0, limit_val_batches: float = 1.0, limit_test_batches: float = 1.0,
                  deterministic: bool = False, strategy: str = "auto", num_nodes: int = 1, sync_batchnorm: bool = False,
-                 default_root_dir: Optional[str] = None, callbacks=None, logger=None, **unused):
+                 default_root_dir: Optional[str] = None, enable_checkpointing: bool = False, callbacks=None, logger=None,
+                 **unused):
         if precision not in ("bf16-mixed", "bf16", "32", "32-true", 32):
             raise ValueError(f"precision {precision!r}: the HIP path computes bf16 GEMMs with fp32 accumulation")
         if accelerator == "cpu":
             raise RuntimeError("accelerator=cpu: this build has no CPU path (the oracle under oracle/ is test-only)")
+        if strategy not in ("auto", "ddp", "ddp_find_unused_parameters_false", "ddp_find_unused_parameters_true", None):
+            raise ValueError(f"strategy {strategy!r}: data parallel (one process per GPU, 'ddp') is the only strategy")
         self.max_epochs, self.max_steps = max_epochs, max_steps
         self.gradient_clip_val = gradient_clip_val
         self.fast_dev_run = fast_dev_run
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
+        self.limit_test_batches = limit_test_batches
         self.log_every_n_steps = log_every_n_steps
+        self.devices, self.strategy, self.num_nodes = devices, strategy, num_nodes
+        self.default_root_dir = default_root_dir
         self.global_step = 0
+        self.current_epoch = 0
         self.estimated_stepping_batches = None
         self.history = []
+        self.callback_metrics: Dict[str, float] = {}
+        # ---- distributed: join the group the launcher described, or fail loudly
+        want = _requested_world(devices, num_nodes)
+        env_rank, env_local, env_W = comm.env_world()
+        if want is not None and want > 1 and env_W == 1 and not comm.is_dist():
+            raise RuntimeError(
+                f"trainer.devices={devices} x num_nodes={num_nodes} asks for {want} ranks but this process was started "
+                f"alone (WORLD_SIZE unset).  Launch one process per GPU: `python -m torch.distributed.run --nnodes=1 "
+                f"--nproc-per-node {want} --master-addr 127.0.0.1 -m spatial_clip_amd.train ...`")
+        if env_W > 1 or comm.is_dist():
+            comm.init_from_env(expect_world=want)
+        self.rank, self.world_size = comm.world()
+        self.is_global_zero = self.rank == 0
+        self.checkpoint_callback: Optional[CheckpointCallback] = None
+        if enable_checkpointing and default_root_dir and not fast_dev_run:
+            self.checkpoint_callback = CheckpointCallback(os.path.join(str(default_root_dir), "checkpoints"))
 
     def _limit(self, n: int, frac) -> int:
         if self.fast_dev_run:
@@ -56,15 +114,26 @@ class Trainer:
         cfg = model.configure_optimizers()
         opt = cfg["optimizer"]
         sched = cfg.get("lr_scheduler", {}).get("scheduler")
+        self.optimizer, self.scheduler = opt, sched
+        start_epoch = 0
+        if ckpt_path:
+            if not os.path.isfile(ckpt_path):
+                raise FileNotFoundError(f"ckpt_path {ckpt_path!r} does not exist")
+            self.global_step = self.load_checkpoint(ckpt_path, model, opt, sched)
+            start_epoch = self.global_step // max(n_train, 1)
         rank, W = comm.world()
         reducer = comm.GradBucketReducer(model.net.store.grad)
-        model.net.grad_bucket_hook = reducer.bucket_ready if W > 1 else None
-        for epoch in range(epochs):
+        model.net.grad_bucket_hook = reducer.bucket_ready if comm.is_dist() else None
+        for epoch in range(start_epoch, epochs):
+            self.current_epoch = epoch
             model.train_metrics.reset()
             t0 = time.time()
+            skip = self.global_step - epoch * n_train if epoch == start_epoch else 0     # mid-epoch resume
             for i, batch in enumerate(train):
                 if i >= n_train or (self.max_steps != -1 and self.global_step >= self.max_steps):
                     break
+                if i < skip:
+                    continue
                 batch = _to_device(batch, model.device)
                 with streams.chain_stream():
                     loss = model.training_step(batch, i)
@@ -78,7 +147,7 @@ class Trainer:
                     self.history.append({"step": self.global_step, "train/loss": float(loss.detach())})
             torch.cuda.synchronize()
             rec = {"epoch": epoch, "time_s": time.time() - t0, **model.train_metrics.compute()}
-            if self.history:
+            if self.history and "train/loss" in self.history[-1]:
                 rec["train/loss"] = self.history[-1]["train/loss"]
             val = datamodule.val_dataloader()
             n_val = self._limit(len(val), self.limit_val_batches)
@@ -98,9 +167,29 @@ class Trainer:
                 if model.zero_shot_metric and model.gene_bank_embeddings is not None:
                     rec["val/zero_shot_pcc"] = model.zero_shot_metric.compute()
             self.history.append(rec)
+            self._checkpoint_epoch(model, opt, sched, rec)
         self.callback_metrics = {k: v for k, v in self.history[-1].items() if isinstance(v, float)} if self.history else {}
 
     # ------------------------------------------------------------------ checkpoints (reference state_dict names)
+    def _checkpoint_epoch(self, model, opt, sched, rec: Dict[str, Any]) -> None:
+        cb = self.checkpoint_callback
+        if cb is None:
+            return
+        if self.is_global_zero:
+            os.makedirs(cb.dirpath, exist_ok=True)
+            last = os.path.join(cb.dirpath, "last.ckpt")
+            self.save_checkpoint(last, model, opt, sched, self.global_step)
+            cb.last_model_path = last
+            score = rec.get(cb.monitor)
+            if isinstance(score, float) and cb.is_better(score):
+                best = os.path.join(cb.dirpath, f"epoch_{int(rec['epoch']):03d}.ckpt")
+                self.save_checkpoint(best, model, opt, sched, self.global_step)
+                if cb.best_model_path and cb.best_model_path != best and os.path.exists(cb.best_model_path):
+                    os.remove(cb.best_model_path)
+                cb.best_model_path, cb.best_model_score = best, score
+        if comm.is_dist():
+            torch.distributed.barrier()
+
     @staticmethod
     def save_checkpoint(path: str, model, optimizer=None, scheduler=None, global_step: int = 0) -> None:
         """``state_dict`` uses the reference ``CLIP.state_dict()`` key names, so the file loads into open_clip too."""
@@ -113,9 +202,11 @@ class Trainer:
 
     @staticmethod
     def load_checkpoint(path: str, model, optimizer=None, scheduler=None) -> int:
-        ck = torch.load(path, map_location="cpu")
-        model.net.load_state_dict(ck["state_dict"])
-        if optimizer is not None and "optimizer" in ck:
+        """Accepts this trainer's files and the reference's Lightning / DDP / plain-CLIP layouts (key prefixes
+        ``net.model.``, ``module.`` are stripped: net.strip_checkpoint_prefix)."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        model.net.load_checkpoint_state_dict(ck, source=path)
+        if optimizer is not None and isinstance(ck.get("optimizer"), dict) and "exp_avg" in ck["optimizer"]:
             optimizer.load_state_dict({k: (v.to(model.device) if isinstance(v, torch.Tensor) else v)
                                        for k, v in ck["optimizer"].items()})
         if scheduler is not None and "scheduler_last_epoch" in ck:
@@ -124,8 +215,16 @@ class Trainer:
         return int(ck.get("global_step", 0))
 
     def test(self, model, datamodule, ckpt_path: Optional[str] = None):
+        if ckpt_path:
+            if not os.path.isfile(ckpt_path):
+                raise FileNotFoundError(f"ckpt_path {ckpt_path!r} does not exist")
+            self.load_checkpoint(ckpt_path, model)
+        if getattr(datamodule, "preprocess_fn", None) is None:
+            datamodule.preprocess_fn = model.net.preprocess_val
+            datamodule.tokenizer = model.net.tokenizer
+            datamodule.setup("test")
         loader = datamodule.test_dataloader()
-        n = self._limit(len(loader), 1.0)
+        n = self._limit(len(loader), self.limit_test_batches)
         model.test_metrics.reset()
         tl = []
         for i, batch in enumerate(loader):
@@ -134,4 +233,5 @@ class Trainer:
             model.test_step(_to_device(batch, model.device), i)
             tl.append(model.logged["test/loss"])
         out = {"test/loss": float(torch.stack(tl).mean()), **model.test_metrics.compute()} if tl else {}
+        self.callback_metrics = {**self.callback_metrics, **{k: v for k, v in out.items() if isinstance(v, float)}}
         return [out]

@@ -85,3 +85,49 @@ def test_single_process_is_identity():
     assert ai is a and at is b and ii is ids
     assert comm.reduce_scatter_sum(a) is a
     assert comm.world() == (0, 1)
+
+
+def _fg_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world)})
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import comm
+    assert comm.init_from_env() == (rank, rank, world)          # gloo on a CPU-only host
+    assert comm.init_from_env(expect_world=world) == (rank, rank, world)   # idempotent
+    try:
+        comm.init_from_env(expect_world=world + 1)
+        raise AssertionError("a world-size mismatch must raise")
+    except RuntimeError as e:
+        assert "WORLD_SIZE" in str(e)
+    g = torch.Generator().manual_seed(100 + rank)
+    B, D = 5, 8
+    img, txt = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+    ids = torch.arange(B) + 1000 * rank + (1 << 40)               # ids beyond 32 bits survive the float payload
+    ref = comm.gather_packed(img, txt, ids, ids + 7)
+    fg = comm.FeatureGather(torch.device("cpu"))
+    fg.begin(ids, ids + 7)
+    fg.put("text", txt)
+    fg.put("image", img)
+    assert fg.has("text", txt) and fg.has("image", img) and fg.with_ids("text") and not fg.with_ids("image")
+    all_t, ids_i, ids_t = fg.take("text")
+    all_i, none_a, none_b = fg.take("image")
+    assert none_a is None and none_b is None
+    assert torch.equal(all_i, ref[0]) and torch.equal(all_t, ref[1])
+    assert torch.equal(ids_i, ref[2]) and torch.equal(ids_t, ref[3])
+    assert all_t.stride(0) == D + 4 and all_i.stride(0) == D      # read in place from the receive buffers
+    fg.begin(None, None)                                           # ClipLoss: no ids travel
+    fg.put("text", txt)
+    assert not fg.with_ids("text") and not fg.has("image", img)
+    assert torch.equal(fg.take("text")[0], ref[1])
+    ret[rank] = fg.launched
+    comm.shutdown()
+
+
+def test_feature_gather_matches_synchronous_gather_two_ranks():
+    mp.set_start_method("spawn", force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_fg_worker, args=(2, 29621, ret), nprocs=2, join=True)
+        assert dict(ret) == {0: 3, 1: 3}

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import spatial_clip_amd  # noqa: F401
-from spatial_clip_amd import _lib, data, model_configs as mc, optim, params
+from spatial_clip_amd import _lib, data, hydra_lite as H, model_configs as mc, optim, params
 from oracle import spatial_clip_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -147,3 +147,47 @@ def test_resize_pos_embed_matches_reference(golden_dir):
     sd = {"other": torch.zeros(1)}
     net.resize_pos_embed(sd, (4, 4))          # no visual embedding: untouched
     assert list(sd) == ["other"]
+
+
+def test_trainer_refuses_a_multi_gpu_config_without_a_launcher(monkeypatch):
+    """configs/trainer/ddp.yaml (devices: 8, strategy: ddp) started as ONE process must fail loudly, not train a
+    single replica that looks like DP8 (reference: Lightning launches the ranks itself, configs/trainer/ddp.yaml:4)."""
+    from spatial_clip_amd import trainer as T
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert T._requested_world("auto", 1) is None and T._requested_world(8, 1) == 8
+    assert T._requested_world([0, 1, 2], 2) == 6 and T._requested_world("4", 1) == 4
+    with pytest.raises(RuntimeError, match="torch.distributed.run"):
+        T.Trainer(devices=8, strategy="ddp", accelerator="gpu")
+    with pytest.raises(ValueError, match="strategy"):
+        T.Trainer(strategy="fsdp")
+    t = T.Trainer(devices=1, default_root_dir="/tmp/x", enable_checkpointing=True)
+    assert t.world_size == 1 and t.checkpoint_callback is not None and t.checkpoint_callback.monitor == "val/R@1"
+    cfg = H.compose("train.yaml", ["experiment=vitb16_gene_8gpu"])
+    assert cfg.trainer.devices == 8 and cfg.trainer.strategy == "ddp"
+    with pytest.raises(RuntimeError, match="8 ranks"):
+        H.instantiate(cfg.trainer)
+
+
+def test_reference_ddp_trainer_config_composes_and_is_enforced(monkeypatch):
+    """The reference's own configs/trainer/ddp.yaml (devices: 4) through the composer."""
+    ref = "/root/reference/configs"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("PROJECT_ROOT", "/tmp")
+    cfg = H.compose("train.yaml", ["trainer=ddp", "logger=null", "callbacks=null"], config_dir=ref)
+    assert cfg.trainer.strategy == "ddp" and cfg.trainer.devices == 4 and cfg.trainer.sync_batchnorm is True
+    with pytest.raises(RuntimeError, match="4 ranks"):
+        H.instantiate(cfg.trainer)
+
+
+def test_checkpoint_prefixes_and_step_output_contract():
+    from spatial_clip_amd import module, net
+    assert net.strip_checkpoint_prefix("net.model.visual.conv1.weight") == "visual.conv1.weight"
+    assert net.strip_checkpoint_prefix("module.visual.proj") == "visual.proj"
+    assert net.strip_checkpoint_prefix("module.net.model.logit_scale") == "logit_scale"
+    assert net.strip_checkpoint_prefix("transformer.resblocks.0.ln_1.weight") == "transformer.resblocks.0.ln_1.weight"
+    out = module.StepOutput({"loss": 1.0, "image_features": None})
+    assert "logits" in out and set(out.keys()) >= {"loss", "logits", "image_features"}     # spatial_clip_module.py:70

@@ -75,3 +75,153 @@ def test_two_ranks_match_single_process():
     for s in range(steps):
         mean2 = 0.5 * (r0["loss"][s] + r1["loss"][s])                         # mean of the per-rank local losses
         assert abs(mean2 - one["loss"][s]) < (4e-3 if s < 2 else 2e-2), (s, mean2, one["loss"][s])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# every (local_loss, gather_with_grad) layout of ClipLoss against the REFERENCE's own 2-rank gloo run
+def _layout_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import losses
+    z = np.load(os.path.join(ROOT, "tests", "golden", "loss_w2.npz"))
+    img, txt, scale = torch.from_numpy(z["img"]), torch.from_numpy(z["txt"]), float(z["scale"])
+    B = img.shape[0] // world
+    sl = slice(rank * B, (rank + 1) * B)
+    out = {}
+    for name, (local_loss, gwg) in {"bg_grad": (True, True), "gg_grad": (False, True), "gg_nograd": (False, False),
+                                    "bg_nograd": (True, False)}.items():
+        i = img[sl].cuda().requires_grad_(True)
+        t = txt[sl].cuda().requires_grad_(True)
+        s = torch.tensor(scale, device="cuda", requires_grad=True)
+        crit = losses.ClipLoss(local_loss=local_loss, gather_with_grad=gwg, cache_labels=True, rank=rank, world_size=world)
+        l = crit(i, t, s)["contrastive_loss"]
+        l.backward()
+        out[name] = {"loss": float(l), "gimg": i.grad.cpu().numpy(), "gtxt": t.grad.cpu().numpy(), "gscale": float(s.grad)}
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_clip_loss_layouts_two_ranks_match_reference():
+    import numpy as np
+    mp.set_start_method("spawn", force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_layout_worker, args=(2, 29721, ret), nprocs=2, join=True)
+        res = dict(ret)
+    zl = np.load(os.path.join(ROOT, "tests", "golden", "loss_w2_layouts.npz"))
+    z0 = np.load(os.path.join(ROOT, "tests", "golden", "loss_w2.npz"))
+    for r in range(2):
+        for name in ("bg_grad", "gg_grad", "gg_nograd", "bg_nograd"):
+            if name == "bg_grad":
+                want = {k: z0[f"r{r}_clip_{k}"] for k in ("loss", "gimg", "gtxt", "gscale")}
+            else:
+                want = {k: zl[f"r{r}_{name}_{k}"] for k in ("loss", "gimg", "gtxt", "gscale")}
+            got = res[r][name]
+            assert abs(got["loss"] - float(want["loss"])) < 5e-6, (r, name)
+            assert abs(got["gscale"] - float(want["gscale"])) < 5e-6, (r, name)
+            np.testing.assert_allclose(got["gimg"], want["gimg"], atol=5e-6, err_msg=f"{r} {name} gimg")
+            np.testing.assert_allclose(got["gtxt"], want["gtxt"], atol=5e-6, err_msg=f"{r} {name} gtxt")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the PRODUCT entry point (train.train: hydra config -> comm.init_from_env -> Trainer.fit) under two ranks, with the
+# feature all-gather on the communication stream vs the synchronous gather: bit-identical weights
+def _entry_worker(rank, world, port, overlap, ret):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank),
+                       "WORLD_SIZE": str(world), "SC_DIST_BACKEND": "gloo", "SC_GATHER_OVERLAP": "1" if overlap else "0",
+                       "PROJECT_ROOT": ROOT})
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import comm, hydra_lite, train
+    cfg = hydra_lite.compose("train.yaml", ["experiment=smoke_shards", "trainer=ddp", f"trainer.devices={world}",
+                                            "trainer.fast_dev_run=false", "trainer.max_epochs=1", "loss=spatial",
+                                            "data.steps_per_epoch=3", "data.batch_size=8", "test=false",
+                                            "model.net.model_name=ViT-Ti-16-gene", "data.n_genes=512"])
+    metrics, obj = train.train(cfg)
+    m = obj["model"]
+    assert comm.world() == (rank, world)
+    assert obj["trainer"].world_size == world
+    fg = m._feature_gather
+    ret[(overlap, rank)] = {"w": m.net.store.master.detach().cpu(), "loss": metrics.get("val/loss"),
+                            "gathers": 0 if fg is None else fg.launched, "device": torch.cuda.current_device()}
+    comm.shutdown()
+
+
+def test_train_entry_point_two_ranks_overlapped_gather_is_bit_identical():
+    mp.set_start_method("spawn", force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_entry_worker, args=(2, 29731, True, ret), nprocs=2, join=True)
+        mp.spawn(_entry_worker, args=(2, 29741, False, ret), nprocs=2, join=True)
+        res = dict(ret)
+    assert res[(True, 0)]["gathers"] >= 6 and res[(False, 0)]["gathers"] == 0     # 3 train steps x (text, image) [+ val]
+    for r in range(2):
+        assert torch.equal(res[(True, r)]["w"], res[(False, r)]["w"]), f"rank {r}: overlapped gather changed the result"
+    assert torch.equal(res[(True, 0)]["w"], res[(True, 1)]["w"]), "ranks diverged"
+    assert torch.isfinite(res[(True, 0)]["w"]).all()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RCCL itself: a ONE-rank nccl group with the distributed code path forced on (SC_FORCE_DIST=1) runs every collective
+# of the step -- packed all-gathers on the communication stream, reduce_scatter_tensor, bucketed async all-reduce -- on
+# the real RCCL backend; at world size 1 they are identities, so the result must equal the plain single-process run
+def _rccl_worker(rank, world, port, force, ret):
+    import sys
+    sys.path.insert(0, ROOT)
+    import functools
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "LOCAL_RANK": "0",
+                       "WORLD_SIZE": "1", "SC_FORCE_DIST": "1" if force else "0"})
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import comm, data, losses, model_configs as mc, module, net, optim
+    comm.init_from_env()
+    if force:
+        import torch.distributed as dist
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and comm.is_dist()
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 64, 2, 32), text=None, gene=mc.GeneCfg(200, 64))
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=3)
+    loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                 neighbor_alpha_scale=0.5, float32_logits=True)
+    m = module.SpatialClipLitModule(
+        n, loss_fn, functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+
+    class T:
+        max_steps, max_epochs, estimated_stepping_batches = 10, None, 10
+    m.trainer = T()
+    oc = m.configure_optimizers()
+    opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+    reducer = comm.GradBucketReducer(n.store.grad, bucket_floats=20000)
+    n.grad_bucket_hook = reducer.bucket_ready if comm.is_dist() else None
+    ls = []
+    for s in range(3):
+        b = data.synthetic_batch(16, 32, 200, 4, s)
+        loss = m.training_step({k: v.cuda() for k, v in b.items()}, s)
+        loss.backward()
+        reducer.finish()
+        opt.step(grad_scale=1.0, max_norm=1.0)
+        sched.step()
+        ls.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    ret[force] = {"w": n.store.master.detach().cpu(), "loss": ls,
+                  "gathers": 0 if m._feature_gather is None else m._feature_gather.launched}
+    comm.shutdown()
+
+
+def test_rccl_one_rank_group_runs_every_collective_and_changes_nothing():
+    mp.set_start_method("spawn", force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rccl_worker, args=(1, 29751, True, ret), nprocs=1, join=True)
+        mp.spawn(_rccl_worker, args=(1, 29752, False, ret), nprocs=1, join=True)
+        res = dict(ret)
+    assert res[True]["gathers"] == 6 and res[False]["gathers"] == 0
+    assert res[True]["loss"] == res[False]["loss"]
+    assert torch.equal(res[True]["w"], res[False]["w"])

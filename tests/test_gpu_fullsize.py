@@ -1,5 +1,6 @@
-"""BASELINE.json full-size configuration (ViT-B/16 + gene-MLP 20000->512->512, local batch 256) checked through
-size-independent properties -- the fp32 CPU oracle cannot run this size in seconds:
+"""BASELINE.json full-size configuration (ViT-B/16 + gene-MLP 20000->512->512, local batch 256): the loss / feature
+deltas against the fp32 oracle's FORWARD at this size (about 10 s of host time), and -- since the oracle's full
+training step does not finish in seconds here -- size-independent properties of the step:
   * determinism: two runs from the same seed give bit-identical losses and gradients (no float atomics on this path);
   * the device grad-norm equals the norm of the flat gradient buffer; clipping scales the AdamW update accordingly;
   * ClipLoss is invariant under a permutation of the batch (rows and columns permuted together);
@@ -98,3 +99,43 @@ def test_vitb16_b256_overfits_one_batch():
     assert ls[-1] < ls[1] - 0.05, ls          # step 0 runs with lr = 0 (LambdaLR), so compare from step 1
     r = m.train_metrics.compute()
     assert 0.0 <= r["train/R@1"] <= r["train/R@10"] <= 1.0
+
+
+@pytest.mark.parametrize("which", ["clip", "spatial"])
+def test_vitb16_b256_loss_within_1e3_of_fp32_oracle(which):
+    """The north-star bound at the headline size: |loss(HIP bf16-mixed) - loss(fp32 oracle)| <= 1e-3 for ClipLoss and
+    SpatialLoss(k=8) on the SAME ViT-B/16 weights and the SAME 256-pair batch (oracle forward only: ~10 s of host time),
+    features within 5e-3."""
+    from oracle import spatial_clip_oracle as O
+    data, losses, module, net, optim = _pkg()
+    B = 256
+    batch = data.synthetic_batch(B, 224, 20000, K=8)
+    if which == "clip":
+        loss_fn = losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True)
+    else:
+        loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                     neighbor_alpha_scale=0.5, float32_logits=True)
+    n, m = _module(net, module, losses, optim, loss_fn, seed=0)
+    with torch.no_grad():
+        out = m.model_step({k: v.cuda() for k, v in batch.items()})
+        torch.cuda.synchronize()
+        v = n.cfg.vision
+        ocfg = O.ModelCfg(n.cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
+                          O.GeneCfg(n.cfg.gene.n_genes, n.cfg.gene.hidden))
+        p = {k: t.cpu() for k, t in n.state_dict().items()}
+        torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+        f = O.net_forward(batch["images"], batch["texts"], p, ocfg)
+        if which == "clip":
+            ref = O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"])
+        else:
+            ref = O.spatial_loss(f["image_features"], f["text_features"], f["logit_scale"], batch["image_tile_ids"],
+                                 batch["text_tile_ids"], batch["neighbor_tile_ids"], batch["neighbor_alphas"])
+    dl = abs(float(out["loss"]) - float(ref))
+    df = max(float((out["image_features"].cpu() - f["image_features"]).abs().max()),
+             float((out["text_features"].cpu() - f["text_features"]).abs().max()))
+    print(f"[fullsize {which}] loss {float(out['loss']):.6f} vs oracle {float(ref):.6f}: |d|={dl:.2e}, max|d feature|={df:.2e}")
+    assert dl <= 1e-3, dl
+    assert df <= 5e-3, df
+    assert out["logits"].shape == (B, B)                   # model_step's output contract (spatial_clip_module.py:66-70)
+    torch.testing.assert_close(out["logits"].cpu(), (f["image_features"] @ f["text_features"].t()) * f["logit_scale"],
+                               atol=14.3 * 5e-3 * 2, rtol=0)

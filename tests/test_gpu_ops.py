@@ -238,3 +238,70 @@ def test_adamw_and_gradnorm():
         ops.adamw_step(pd, gr.cuda(), md, vd, n, 1e-3, 0.9, 0.98, 1e-6, 0.1, step, 1.0 / W, nc, pbf)
         torch.testing.assert_close(pd.cpu(), pr, atol=2e-6, rtol=1e-5)
         assert torch.equal(pbf.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (6, 6, 32), (64, 64, 32), (65, 63, 33), (256, 2048, 512), (128, 1100, 96),
+                                   (2048, 512, 256), (300, 260, 1027)])
+def test_sgemm_mfma_every_layout_is_exact_fp32(M, N, K):
+    """The exact-fp32 MFMA head GEMM against float64 on small-integer-free random data: every operand layout
+    (k-contiguous / m- or n-contiguous), ragged edges, accumulate, 64- and 128-tiles (the latter via a large group)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    ref = (a.double() @ b.double().t())
+    tol = 2e-6 * K ** 0.5 * 4
+    ad, bd = a.cuda(), b.cuda()
+    at, bt = a.t().contiguous().cuda(), b.t().contiguous().cuda()
+    for (A, sam, sak) in ((ad, K, 1), (at, 1, M)):
+        for (B_, sbn, sbk) in ((bd, K, 1), (bt, 1, N)):
+            c = torch.full((M, N), float("nan"), device="cuda")
+            ops.sgemm(A, sam, sak, B_, sbn, sbk, c, N, M, N, K)
+            err = (c.double().cpu() - ref).abs().max().item()
+            assert err <= tol, (sam, sak, sbn, sbk, err)
+    # strided output + accumulate, operands with padded row strides (as the gathered features have)
+    pad = torch.zeros(M, K + 4, device="cuda"); pad[:, :K] = ad
+    c2 = torch.ones(M, N + 8, device="cuda")
+    ops.sgemm(pad, K + 4, 1, bd, K, 1, c2, N + 8, M, N, K, accumulate=True)
+    assert (c2[:, :N].double().cpu() - (ref + 1)).abs().max().item() <= tol
+    assert torch.equal(c2[:, N:], torch.ones(M, 8, device="cuda"))
+
+
+def test_sgemm_grouped_matches_single_launches_bitwise():
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    B, G, D = 48, 200, 64
+    f = torch.randn(B, D, generator=g).cuda(); a = torch.randn(G, D, generator=g).cuda()
+    dz = torch.randn(B, G, generator=g).cuda()
+    z1, z2 = torch.empty(B, G, device="cuda"), torch.empty(B, G, device="cuda")
+    d1, d2 = torch.empty(B, D, device="cuda"), torch.empty(G, D, device="cuda")
+    ops.sgemm_grouped([(f, D, 1, a, D, 1, z1, G, B, G, D), (dz, G, 1, a, 1, D, d1, D, B, D, G),
+                       (dz, 1, G, f, 1, D, d2, D, G, D, B), (f, D, 1, a, D, 1, z2, G, B, G, D)])
+    s1, s2, s3 = torch.empty_like(z1), torch.empty_like(d1), torch.empty_like(d2)
+    ops.sgemm(f, D, 1, a, D, 1, s1, G, B, G, D)
+    ops.sgemm(dz, G, 1, a, 1, D, s2, D, B, D, G)
+    ops.sgemm(dz, 1, G, f, 1, D, s3, D, G, D, B)
+    assert torch.equal(z1, s1) and torch.equal(z2, s1) and torch.equal(d1, s2) and torch.equal(d2, s3)
+    torch.testing.assert_close(z1.cpu(), (f @ a.t()).cpu(), atol=1e-4, rtol=1e-4)
+    # 128x128 tiles: a group whose problems are all large
+    M = N = 4096
+    x = torch.randn(M, 96, generator=g).cuda(); y = torch.randn(N, 96, generator=g).cuda()
+    c = torch.empty(M, N, device="cuda")
+    ops.sgemm(x, 96, 1, y, 96, 1, c, N, M, N, 96)
+    assert (c.double() - x.double() @ y.double().t()).abs().max().item() < 1e-4
+
+
+def test_pack_rows_round_trip():
+    ops = _ops()
+    B, D = 37, 64
+    f = torch.randn(B, D, device="cuda")
+    ia = torch.arange(B, device="cuda", dtype=torch.int64) + (1 << 41)
+    ib = -ia
+    out = torch.zeros(B, D + 4, device="cuda")
+    ops.pack_rows(f, ia, ib, out)
+    assert torch.equal(out[:, :D], f)
+    assert torch.equal(out[:, D:D + 2].contiguous().view(torch.int64).view(-1), ia)
+    assert torch.equal(out[:, D + 2:].contiguous().view(torch.int64).view(-1), ib)
+    out2 = torch.zeros(B, D, device="cuda")
+    ops.pack_rows(f, None, None, out2)
+    assert torch.equal(out2, f)
