@@ -1,0 +1,148 @@
+// Shared pieces of the attention kernels (sc_attention.hip: one workgroup per head, register-staged loads;
+// sc_attention_p.hip: persistent workgroups, LDS-DMA double buffering): the swizzled LDS image that serves both row
+// reads (ds_read_b128) and transposed reads (ds_read_b64_tr_b16), fragment accessors, quad reductions by
+// v_permlane16/32_swap, raw v_exp_f32.
+#pragma once
+#include "sc_common.h"
+#include "sc_kernels.h"
+
+// sc_attention_p.hip: persistent LDS-DMA forward; returns 1 when it took the launch, 0 when the shape is out of its range
+int sc_attn_fwd_persistent(const void* qkv, void* out, float* lse, int B, int L, int Lq, int H, int dh, int causal,
+                           hipStream_t st);
+
+namespace {
+
+constexpr int MAXL = 320;
+
+template <int DH>
+struct Img {
+    // image of [rows][DH] bf16, row = DH*2 bytes, 16-byte chunks XOR-swizzled so that b128 row reads and
+    // tr_b16 reads are both bank-conflict free (derivation in DESIGN.md).
+    static constexpr int ROWB = DH * 2;
+    static SC_DEVICE int swz(int row) { return DH == 64 ? (((row >> 1) & 3) << 1) : (((row >> 2) & 1) << 1); }
+    static SC_DEVICE int off(int row, int chunk16) { return row * ROWB + ((chunk16 ^ swz(row)) << 4); }
+};
+
+// cooperative load of rows [0,L) x DH of one head into TWO LDS images (K and V, or Q and dO), zero-filling rows
+// [L, Lp).  All the 16-byte loads of a batch (4 per image and thread) are issued before the first LDS store, so a
+// workgroup pays ONE global-memory round trip for both images instead of one per loop trip.
+template <int DH>
+SC_DEVICE void load_images2(char* img_a, const bf16* src_a, long long stride_a, char* img_b, const bf16* src_b,
+                            long long stride_b, int L, int Lp, int t) {
+    constexpr int CH = DH / 8, NB = 4;
+    const int total = Lp * CH, step = blockDim.x;
+    for (int c0 = t; c0 < total; c0 += NB * step) {
+        u32x4 va[NB], vb[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u * step;
+            const int row = c / CH, ch = c % CH;
+            va[u] = (u32x4){0u, 0u, 0u, 0u};
+            vb[u] = (u32x4){0u, 0u, 0u, 0u};
+            if (c < total && row < L) {
+                va[u] = *reinterpret_cast<const u32x4*>(src_a + (long long)row * stride_a + ch * 8);
+                vb[u] = *reinterpret_cast<const u32x4*>(src_b + (long long)row * stride_b + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u * step;
+            if (c < total) {
+                const int row = c / CH, ch = c % CH;
+                *reinterpret_cast<u32x4*>(img_a + Img<DH>::off(row, ch)) = va[u];
+                *reinterpret_cast<u32x4*>(img_b + Img<DH>::off(row, ch)) = vb[u];
+            }
+        }
+    }
+}
+
+// Four images (Q, K, V of one head out of the packed qkv rows, and dO) with every global load of a batch in flight
+// before the first LDS store: the fused backward kernel pays one memory round trip for all its LDS-resident operands.
+template <int DH>
+SC_DEVICE void load_images4(char* const (&img)[4], const bf16* const (&src)[4], const long long (&stride)[4], int L, int Lp,
+                            int t) {
+    constexpr int CH = DH / 8, NB = 3;
+    const int total = Lp * CH, step = blockDim.x;
+    for (int c0 = t; c0 < total; c0 += NB * step) {
+        u32x4 v[4][NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u * step;
+            const int row = c / CH, ch = c % CH;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k][u] = (u32x4){0u, 0u, 0u, 0u};
+                if (c < total && row < L) v[k][u] = *reinterpret_cast<const u32x4*>(src[k] + (long long)row * stride[k] + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = c0 + u * step;
+            if (c < total) {
+                const int row = c / CH, ch = c % CH;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(img[k] + Img<DH>::off(row, ch)) = v[k][u];
+            }
+        }
+    }
+}
+
+// A/B fragment by row read: lane (g,i) gets img[row0+i][ks*32 + 8g .. +7]
+template <int DH>
+SC_DEVICE bf16x8 frag_row(const char* img, int row0, int ks, int li, int lg) {
+    return *reinterpret_cast<const bf16x8*>(img + Img<DH>::off(row0 + li, ks * 4 + lg));
+}
+
+// transposed fragment over a 32-row block starting at row0 for the 16 columns [c0, c0+16):
+// lane (g,i) gets img[row0 + slot(g,j)][c0 + i], j = 0..7
+template <int DH>
+SC_DEVICE bf16x8 frag_tr(const char* img, int row0, int c0, int li, int lg) {
+    const int q = li >> 2, p = li & 3;
+    const int r1 = row0 + 4 * lg + q, r2 = r1 + 16;
+    const int ch = (c0 >> 3) + (p >> 1);
+    const bf16x4 lo = sc_lds_tr16(img + Img<DH>::off(r1, ch) + ((p & 1) << 3));
+    const bf16x4 hi = sc_lds_tr16(img + Img<DH>::off(r2, ch) + ((p & 1) << 3));
+    return sc_cat(lo, hi);
+}
+
+SC_DEVICE bf16x8 pack8(f32x4 a, f32x4 b) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = (bf16)a[e]; r[4 + e] = (bf16)b[e]; }
+    return r;
+}
+
+// exchange with the lane 16 / 32 positions away without LDS: v_permlane{16,32}_swap on (v, v) leaves the partner's
+// value in one of the two results in every lane -> xor-16 / xor-32 butterflies in one VALU instruction each
+SC_DEVICE float xor16(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    // r[0]: odd 16-lane rows hold the even neighbour's value; r[1]: even rows hold the odd neighbour's value
+    const bool odd = (threadIdx.x & 16) != 0;
+    return __builtin_bit_cast(float, odd ? r[0] : r[1]);
+}
+SC_DEVICE float xor32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const bool hi = (threadIdx.x & 32) != 0;
+    return __builtin_bit_cast(float, hi ? r[0] : r[1]);
+}
+SC_DEVICE float quad_max(float v) {  // over the 4 lanes that share lane&15
+    v = fmaxf(v, xor16(v));
+    return fmaxf(v, xor32(v));
+}
+SC_DEVICE float quad_sum(float v) {
+    v += xor16(v);
+    return v + xor32(v);
+}
+// raw v_exp_f32 (2^x): arguments here are <= 0 or moderately positive; results below the normal range flush to 0,
+// which is what a masked / far-below-max probability should be (exp2f() adds 5 range-fixup instructions per call)
+SC_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// 2^(x * c + b) on four values: the affine part as packed f32 math (v_pk_fma_f32), then four v_exp_f32
+SC_DEVICE f32x4 exp2_affine(f32x4 x, float c, float b) {
+    const f32x4 a = x * c + b;
+    return (f32x4){fast_exp2(a[0]), fast_exp2(a[1]), fast_exp2(a[2]), fast_exp2(a[3])};
+}
+
+
+}  // namespace

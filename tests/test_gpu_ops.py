@@ -53,6 +53,33 @@ def test_attention_fwd_bwd(B, L, H, dh, causal):
     torch.testing.assert_close(dqkv.float().cpu(), x.grad, atol=4e-2, rtol=4e-2)
 
 
+@pytest.mark.parametrize("B,L,H,causal,q_rows", [(64, 197, 12, False, 0), (110, 77, 8, True, 0), (70, 197, 12, False, 1),
+                                                 (300, 33, 3, False, 0), (37, 224, 9, True, 0)])
+def test_attention_fwd_persistent_walks_many_heads(B, L, H, causal, q_rows):
+    """More heads than CUs: every persistent workgroup walks several heads through its LDS double buffer (the DMA of
+    head i+1 lands while head i computes; counted vmcnt past the previous head's stores).  Run twice: the second launch
+    must reproduce the first bit for bit (no dependence on what an earlier head left in LDS)."""
+    ops = _ops()
+    dh = 64
+    d = H * dh
+    g = torch.Generator().manual_seed(B + L)
+    qkv = bf(torch.randn(B * L, 3 * d, generator=g))
+    o_ref, lse_ref = ref_attn(qkv.float(), B, L, H, dh, causal)
+    out = torch.full((B * L, d), 7.0, dtype=torch.bfloat16, device="cuda")
+    lse = torch.full((B, H, L), 7.0, device="cuda")
+    qd = qkv.cuda()
+    ops.attn_fwd(qd, B, L, H, dh, causal, out=out, lse=lse, q_rows=q_rows)
+    out2 = torch.full_like(out, 3.0); lse2 = torch.full_like(lse, 3.0)
+    ops.attn_fwd(qd, B, L, H, dh, causal, out=out2, lse=lse2, q_rows=q_rows)
+    nq = q_rows if q_rows else L
+    o = out.float().cpu().view(B, L, d); o2 = out2.float().cpu().view(B, L, d)
+    torch.testing.assert_close(o[:, :nq], o_ref.view(B, L, d)[:, :nq], atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(lse.cpu()[:, :, :nq], lse_ref[:, :, :nq], atol=2e-3, rtol=1e-3)
+    assert torch.equal(o[:, :nq], o2[:, :nq]) and torch.equal(lse.cpu()[:, :, :nq], lse2.cpu()[:, :, :nq])
+    if nq < L:                                          # rows past q_rows are not written
+        assert bool((o[:, nq:] == 7.0).all()) and bool((lse.cpu()[:, :, nq:] == 7.0).all())
+
+
 @pytest.mark.parametrize("rows,d", [(50, 768), (197 * 2, 192), (33, 64), (7, 1024)])
 def test_layernorm_fwd_bwd(rows, d):
     ops = _ops()
