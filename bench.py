@@ -28,7 +28,12 @@ def flops_per_pair(cfg, G: int) -> float:
     fwd = 2.0 * (L - 1) * kp * d
     per_layer = 2.0 * L * d * 3 * d + 2 * (2.0 * L * L * d) + 2.0 * L * d * d + 2 * (2.0 * L * d * mlp)
     fwd += v.layers * per_layer + 2.0 * d * D
-    if cfg.gene is not None:
+    if cfg.gene is not None and cfg.gene.kind == "transformer":
+        g = cfg.gene
+        gl, gd, gm = g.tokens, g.width, int(g.width * g.mlp_ratio)
+        fwd += 2.0 * (gl - 1) * g.patch * gd + 2.0 * gd * D
+        fwd += g.layers * (2.0 * gl * gd * 3 * gd + 2 * (2.0 * gl * gl * gd) + 2.0 * gl * gd * gd + 2 * (2.0 * gl * gd * gm))
+    elif cfg.gene is not None:
         fwd += 2.0 * cfg.gene.n_genes * cfg.gene.hidden + 2.0 * cfg.gene.hidden * D
     fwd += 4.0 * G * D
     return 3.0 * fwd
@@ -75,8 +80,9 @@ def cpu_model_string() -> str:
 def _oracle_cfg(cfg):
     from oracle import spatial_clip_oracle as O
     v = cfg.vision
+    g = cfg.gene
     return O.ModelCfg(cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
-                      O.GeneCfg(cfg.gene.n_genes, cfg.gene.hidden))
+                      O.GeneCfg(g.n_genes, g.hidden, g.kind, g.patch, g.width, g.layers, g.head_width, g.mlp_ratio))
 
 
 def cpu_baseline_leg(model_name: str, n_genes: int, B: int, steps: int = 3, loss: str = "clip"):
@@ -368,10 +374,13 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"{args.model} image tower + gene-MLP({args.n_genes}->{cfg.gene.hidden}->{cfg.embed_dim}), "
+               "config": {"workload": f"{args.model} image tower + " + (
+                          f"gene-MLP({args.n_genes}->{cfg.gene.hidden}->{cfg.embed_dim}), " if cfg.gene.kind == "mlp" else
+                          f"{cfg.gene.layers}-layer gene transformer({args.n_genes} genes -> {cfg.gene.tokens} tokens x "
+                          f"{cfg.gene.width}, embed {cfg.embed_dim}), ") + (
                                       f"{cfg.vision.image_size}x{cfg.vision.image_size} tiles, local batch {B}, "
                                       f"{'ClipLoss' if args.loss == 'clip' else 'SpatialLoss(k=8)'} over global batch {G}, "
-                                      "fwd+bwd+grad-allreduce+clip+AdamW", "global_batch": G,
+                                      "fwd+bwd+grad-allreduce+clip+AdamW"), "global_batch": G,
                           "parallelism": f"dp{world}", "loss": float(loss.detach())},
                "n_gpus_live": dist.get_world_size() if world > 1 else 1,
                "loss_delta_vs_oracle": None if delta is None else delta["loss_delta_vs_oracle"],

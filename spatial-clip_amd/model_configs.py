@@ -44,8 +44,27 @@ class TextCfg:
 
 @dataclass
 class GeneCfg:
+    """Gene-expression tower (no reference symbol: SURVEY.md 8a row G).  ``kind="mlp"``: n_genes -> hidden -(GELU)->
+    embed_dim (BASELINE configs[0]-[3]).  ``kind="transformer"`` (configs[4]): the expression vector is cut into
+    ceil(n_genes / patch) contiguous patches of ``patch`` genes (zero padded), each embedded by one bias-free linear
+    map -- a 1-D ViT patch embedding -- then class token + learned positions, ln_pre, ``layers`` pre-LN residual
+    attention blocks (the reference's ResidualAttentionBlock), ln_post on the class token, projection to embed_dim."""
     n_genes: int = 20000
     hidden: int = 512
+    kind: str = "mlp"
+    patch: int = 256
+    width: int = 512
+    layers: int = 6
+    head_width: int = 64
+    mlp_ratio: float = 4.0
+
+    @property
+    def tokens(self) -> int:
+        return (self.n_genes + self.patch - 1) // self.patch + 1
+
+    @property
+    def heads(self) -> int:
+        return self.width // self.head_width
 
 
 @dataclass
@@ -73,10 +92,14 @@ _REGISTRY: Dict[str, ModelCfg] = {
 
 
 def get_model_config(model_name: str, n_genes: Optional[int] = None, gene_hidden: Optional[int] = None) -> ModelCfg:
-    """``ViT-B-16`` -> reference architecture (vision + CLIP text tower); ``ViT-B-16-gene`` -> gene-MLP tower."""
+    """``ViT-B-16`` -> reference architecture (vision + CLIP text tower); ``ViT-B-16-gene`` -> gene-MLP tower;
+    ``ViT-L-14-genetr`` -> 6-layer gene transformer tower (BASELINE configs[4])."""
     name = model_name
     gene = False
-    if name.endswith("-gene"):
+    kind = "mlp"
+    if name.endswith("-genetr"):
+        name, gene, kind = name[:-7], True, "transformer"
+    elif name.endswith("-gene"):
         name, gene = name[:-5], True
     if name not in _REGISTRY:
         # same failure mode as open_clip.factory.create_model (factory.py:399-402)
@@ -86,9 +109,9 @@ def get_model_config(model_name: str, n_genes: Optional[int] = None, gene_hidden
                    cfg.init_logit_scale)
     if gene:
         cfg.text = None
-        cfg.gene = GeneCfg(n_genes or 20000, gene_hidden or 512)
+        cfg.gene = GeneCfg(n_genes or 20000, gene_hidden or 512, kind=kind)
     return cfg
 
 
 def list_models():
-    return list(_REGISTRY) + [n + "-gene" for n in _REGISTRY]
+    return list(_REGISTRY) + [n + "-gene" for n in _REGISTRY] + [n + "-genetr" for n in _REGISTRY]

@@ -21,7 +21,7 @@ import torch
 from . import ops
 from .model_configs import ModelCfg, get_model_config
 from .params import ParamStore
-from .towers import GeneTower, TextTower, VisionTower
+from .towers import GeneTower, GeneTransformerTower, TextTower, VisionTower
 
 OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)   # src/open_clip/constants.py:1-2
 OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -141,7 +141,11 @@ class SpatialClipNet(torch.nn.Module):
             p._sc_store = self.store
             self.register_parameter(name.replace(".", "__"), p)
         self.vision = VisionTower(self.cfg, self.store)
-        self.second = GeneTower(self.cfg, self.store) if self.cfg.gene is not None else TextTower(self.cfg, self.store)
+        if self.cfg.gene is not None:
+            gene_cls = GeneTransformerTower if self.cfg.gene.kind == "transformer" else GeneTower
+            self.second = gene_cls(self.cfg, self.store)
+        else:
+            self.second = TextTower(self.cfg, self.store)
         self.model = _ClipFacade(self)
         self.preprocess_train = self.preprocess_val = self._preprocess
         self.tokenizer = self._tokenizer

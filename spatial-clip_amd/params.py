@@ -98,7 +98,20 @@ def build_specs(cfg: ModelCfg) -> List[ParamSpec]:
         specs.append(ParamSpec("ln_final.weight", (t.width,), "ones"))
         specs.append(ParamSpec("ln_final.bias", (t.width,), "zeros"))
         specs.append(ParamSpec("text_projection", (t.width, cfg.embed_dim), f"normal:{t.width ** -0.5}"))
-    if cfg.gene is not None:
+    if cfg.gene is not None and cfg.gene.kind == "transformer":
+        g = cfg.gene
+        gd = g.width
+        specs.append(ParamSpec("gene.conv1.weight", (gd, g.patch), f"uniform:{1.0 / math.sqrt(g.patch)}"))
+        specs.append(ParamSpec("gene.class_embedding", (gd,), f"normal:{gd ** -0.5}"))
+        specs.append(ParamSpec("gene.positional_embedding", (g.tokens, gd), f"normal:{gd ** -0.5}"))
+        specs.append(ParamSpec("gene.ln_pre.weight", (gd,), "ones"))
+        specs.append(ParamSpec("gene.ln_pre.bias", (gd,), "zeros"))
+        for i in range(g.layers):
+            specs += _block_specs(f"gene.transformer.resblocks.{i}.", gd, int(gd * g.mlp_ratio))
+        specs.append(ParamSpec("gene.ln_post.weight", (gd,), "ones"))
+        specs.append(ParamSpec("gene.ln_post.bias", (gd,), "zeros"))
+        specs.append(ParamSpec("gene.proj", (gd, cfg.embed_dim), f"normal:{gd ** -0.5}"))
+    elif cfg.gene is not None:
         g = cfg.gene
         specs.append(ParamSpec("gene.fc1.weight", (g.hidden, g.n_genes), f"uniform:{1.0 / math.sqrt(g.n_genes)}"))
         specs.append(ParamSpec("gene.fc1.bias", (g.hidden,), f"uniform:{1.0 / math.sqrt(g.n_genes)}"))
@@ -227,7 +240,13 @@ class ParamStore:
             for i in range(t.layers):
                 block(f"transformer.resblocks.{i}.", t.width, int(t.width * t.mlp_ratio))
             self._add_copy("text_projection", cfg.embed_dim, t.width, stored_kn=True)
-        if cfg.gene is not None:
+        if cfg.gene is not None and cfg.gene.kind == "transformer":
+            g = cfg.gene
+            self._add_copy("gene.conv1.weight", g.width, g.patch, need_wb=False)
+            for i in range(g.layers):
+                block(f"gene.transformer.resblocks.{i}.", g.width, int(g.width * g.mlp_ratio))
+            self._add_copy("gene.proj", cfg.embed_dim, g.width, stored_kn=True)
+        elif cfg.gene is not None:
             g = cfg.gene
             self._add_copy("gene.fc1.weight", g.hidden, g.n_genes, need_wb=False)
             self._add_copy("gene.fc2.weight", cfg.embed_dim, g.hidden)

@@ -312,55 +312,61 @@ class TransformerStack:
             main.wait_event(ev)
         return dres
 
-class VisionTower:
-    """VisionTransformer (pool 'tok', learnable pos-embed, ln_pre/ln_post, output projection) + L2 normalise."""
+class PatchTransformerTower:
+    """Patch embedding (one bias-free linear map per patch) + class token + learned positions + ln_pre + N residual
+    attention blocks + ln_post on the class token (pool 'tok') + output projection + L2 normalise.  The image tower
+    (VisionTransformer, src/open_clip/transformer.py:583-918) and the gene transformer (configs[4]; 1-D patches of the
+    expression vector) are both instances: they differ in how the [B * patches, patch_dim] operand is formed
+    (``_patchify``) and in the parameter-name prefix."""
 
-    def __init__(self, cfg: ModelCfg, store: ParamStore):
-        v = cfg.vision
-        self.cfg, self.v, self.s = cfg, v, store
-        self.d, self.D, self.L = v.width, cfg.embed_dim, v.tokens
-        self.kp = 3 * v.patch_size * v.patch_size
-        self.kp_pad = store.copies["visual.conv1.weight"].k_pad
-        self.stack = TransformerStack(store, "visual.transformer.resblocks.", v.width, v.heads, v.layers,
-                                      int(v.width * v.mlp_ratio), causal=False, cls_only_last=True)
+    prefix = "visual."
+
+    def __init__(self, cfg: ModelCfg, store: ParamStore, width: int, heads: int, layers: int, mlp_ratio: float,
+                 tokens: int, patch_dim: int):
+        self.cfg, self.s = cfg, store
+        self.d, self.D, self.L = width, cfg.embed_dim, tokens
+        self.n_layers = layers
+        self.kp = patch_dim
+        self.kp_pad = store.copies[self.prefix + "conv1.weight"].k_pad
+        self.stack = TransformerStack(store, self.prefix + "transformer.resblocks.", width, heads, layers,
+                                      int(width * mlp_ratio), causal=False, cls_only_last=True)
         self.bufs = _Bufs(store.device)
 
+    def _n(self, leaf: str) -> str:
+        return self.prefix + leaf
+
     def param_names_head(self) -> List[str]:
-        return ["visual.ln_post.weight", "visual.ln_post.bias", "visual.proj"]
+        return [self._n("ln_post.weight"), self._n("ln_post.bias"), self._n("proj")]
 
     def param_names_stem(self) -> List[str]:
-        return ["visual.conv1.weight", "visual.class_embedding", "visual.positional_embedding",
-                "visual.ln_pre.weight", "visual.ln_pre.bias"]
+        return [self._n("conv1.weight"), self._n("class_embedding"), self._n("positional_embedding"),
+                self._n("ln_pre.weight"), self._n("ln_pre.bias")]
 
-    def forward(self, images: torch.Tensor) -> torch.Tensor:
-        s, v, d, D, L = self.s, self.v, self.d, self.D, self.L
-        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != v.image_size or images.shape[3] != v.image_size:
-            raise ValueError(f"images must be [B,3,{v.image_size},{v.image_size}], got {tuple(images.shape)}")
-        images = images.contiguous().float()
-        B = images.shape[0]
+    def _patchify(self, x: torch.Tensor) -> torch.Tensor:
+        """-> bf16 [B * (L - 1), kp_pad] patch rows (sets self.B)."""
+        raise NotImplementedError
+
+    def forward(self, inp: torch.Tensor) -> torch.Tensor:
+        s, d, D, L = self.s, self.d, self.D, self.L
+        patches = self._patchify(inp)
+        B = self.B
         M, Mp = B * L, B * (L - 1)
-        self.B = B
         bf = self.bufs
-        patches = bf.get("patches", (Mp, self.kp_pad), BF16)
-        if self.kp_pad != self.kp and getattr(self, "_pad_zeroed", None) is not patches:
-            patches.zero_()            # the K padding must be finite zeros; im2col only writes the real columns
-            self._pad_zeroed = patches
-        ops.im2col(images, patches, v.patch_size)
         patch_out = bf.get("patch_out", (Mp, d), F32)
-        ops.gemm(ops.NT, ops.EPI_F32, patches, s.copies["visual.conv1.weight"].wf, patch_out, M=Mp, N=d, K=self.kp_pad)
+        ops.gemm(ops.NT, ops.EPI_F32, patches, s.copies[self._n("conv1.weight")].wf, patch_out, M=Mp, N=d, K=self.kp_pad)
         x0 = bf.get("x0", (M, d), F32)
-        ops.embed_ln_fwd(patch_out, s.p("visual.class_embedding"), s.p("visual.positional_embedding"),
-                         s.p("visual.ln_pre.weight"), s.p("visual.ln_pre.bias"), x0,
+        ops.embed_ln_fwd(patch_out, s.p(self._n("class_embedding")), s.p(self._n("positional_embedding")),
+                         s.p(self._n("ln_pre.weight")), s.p(self._n("ln_pre.bias")), x0,
                          bf.get("m_pre", (M,), F32), bf.get("r_pre", (M,), F32), B, L, d)
         xf = self.stack.forward(x0, B, L)
         self.xf = xf
         pooled = bf.get("pooled", (B, d), BF16)
         self.x_ld = d if self.stack.cls_only_last else L * d          # xf is compact [B, d] in CLS-only mode
-        ops.layernorm_fwd(xf, s.p("visual.ln_post.weight"), s.p("visual.ln_post.bias"), pooled,
+        ops.layernorm_fwd(xf, s.p(self._n("ln_post.weight")), s.p(self._n("ln_post.bias")), pooled,
                           bf.get("m_post", (B,), F32), bf.get("r_post", (B,), F32), B, d, ldx=self.x_ld)
         f_raw = bf.get("f_raw", (B, D), F32)
-        ops.gemm(ops.NT, ops.EPI_F32, pooled, s.copies["visual.proj"].wf, f_raw, M=B, N=D, K=d)
-        f = torch.empty((B, D), dtype=F32, device=images.device)
+        ops.gemm(ops.NT, ops.EPI_F32, pooled, s.copies[self._n("proj")].wf, f_raw, M=B, N=D, K=d)
+        f = torch.empty((B, D), dtype=F32, device=inp.device)
         ops.l2norm_fwd(f_raw, f, None, bf.get("inv", (B,), F32), B, D)
         self.f = f
         return f
@@ -377,10 +383,10 @@ class VisionTower:
         ops.l2norm_bwd(d_f.contiguous().float(), self.f, bf.get("inv", (B,), F32), d_raw, B, D)
         pooled = bf.get("pooled", (B, d), BF16)
         d_pooled = bf.get("d_pooled", (B, d), BF16)
-        cp = s.copies["visual.proj"]
+        cp = s.copies[self._n("proj")]
         ops.gemm(ops.NT, ops.EPI_BF16, d_raw, cp.wb, d_pooled, M=B, N=d, K=D)
-        ops.gemm(ops.TN, ops.EPI_F32, pooled, d_raw, s.g("visual.proj"), M=d, N=D, K=B)
-        last = self.v.layers - 1
+        ops.gemm(ops.TN, ops.EPI_F32, pooled, d_raw, s.g(self._n("proj")), M=d, N=D, K=B)
+        last = self.n_layers - 1
         if self.stack.cls_only_last:
             dres = bf.get("dres_c", (B, d), F32)
             dres_bf = bf.get("dres_c_bf", (B, d), BF16)
@@ -392,24 +398,77 @@ class VisionTower:
             dres_bf.zero_()
             ld = L * d
         ops.layernorm_bwd(d_pooled, self.xf, bf.get("m_post", (B,), F32), bf.get("r_post", (B,), F32),
-                          s.p("visual.ln_post.weight"), dres, dres_bf, s.g("visual.ln_post.weight"),
-                          s.g("visual.ln_post.bias"), s.g(f"visual.transformer.resblocks.{last}.mlp.c_proj.bias"),
+                          s.p(self._n("ln_post.weight")), dres, dres_bf, s.g(self._n("ln_post.weight")),
+                          s.g(self._n("ln_post.bias")), s.g(self._n(f"transformer.resblocks.{last}.mlp.c_proj.bias")),
                           B, d, accumulate=False, ldx=self.x_ld, lddres=ld, lddbf=ld)
         if on_bucket is not None:
             on_bucket(self.param_names_head())
         cb = (lambda i: on_bucket(self.stack.layer_param_names(i))) if on_bucket is not None else None
         dres = self.stack.backward(dres, dres_bf, last_bias_colsum_done=True, on_layer_done=cb)
-        # stem: ln_pre / positional / class embedding / conv1 (no gradient flows to the pixels)
+        # stem: ln_pre / positional / class embedding / patch embedding (no gradient flows to the input)
         dpatch = bf.get("dpatch", (Mp, d), BF16)
-        ops.embed_ln_bwd(dres, bf.get("patch_out", (Mp, d), F32), s.p("visual.class_embedding"),
-                         s.p("visual.positional_embedding"), bf.get("m_pre", (M,), F32), bf.get("r_pre", (M,), F32),
-                         s.p("visual.ln_pre.weight"), dpatch, s.g("visual.ln_pre.weight"), s.g("visual.ln_pre.bias"),
-                         s.g("visual.positional_embedding"), s.g("visual.class_embedding"), B, L, d)
-        gw = s.g("visual.conv1.weight").view(d, self.kp)
+        ops.embed_ln_bwd(dres, bf.get("patch_out", (Mp, d), F32), s.p(self._n("class_embedding")),
+                         s.p(self._n("positional_embedding")), bf.get("m_pre", (M,), F32), bf.get("r_pre", (M,), F32),
+                         s.p(self._n("ln_pre.weight")), dpatch, s.g(self._n("ln_pre.weight")), s.g(self._n("ln_pre.bias")),
+                         s.g(self._n("positional_embedding")), s.g(self._n("class_embedding")), B, L, d)
+        gw = s.g(self._n("conv1.weight")).view(d, self.kp)
         ops.gemm(ops.TN, ops.EPI_F32, dpatch, bf.get("patches", (Mp, self.kp_pad), BF16), gw, M=d, N=self.kp, K=Mp,
                  splitk=_splitk_for(d, self.kp, Mp))
         if on_bucket is not None:
             on_bucket(self.param_names_stem())
+
+
+class VisionTower(PatchTransformerTower):
+    """VisionTransformer (pool 'tok', learnable pos-embed, ln_pre/ln_post, output projection) + L2 normalise."""
+
+    prefix = "visual."
+
+    def __init__(self, cfg: ModelCfg, store: ParamStore):
+        v = cfg.vision
+        self.v = v
+        super().__init__(cfg, store, v.width, v.heads, v.layers, v.mlp_ratio, v.tokens, 3 * v.patch_size * v.patch_size)
+
+    def _patchify(self, images: torch.Tensor) -> torch.Tensor:
+        v = self.v
+        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != v.image_size or images.shape[3] != v.image_size:
+            raise ValueError(f"images must be [B,3,{v.image_size},{v.image_size}], got {tuple(images.shape)}")
+        images = images.contiguous().float()
+        self.B = B = images.shape[0]
+        patches = self.bufs.get("patches", (B * (self.L - 1), self.kp_pad), BF16)
+        if self.kp_pad != self.kp and getattr(self, "_pad_zeroed", None) is not patches:
+            patches.zero_()            # the K padding must be finite zeros; im2col only writes the real columns
+            self._pad_zeroed = patches
+        ops.im2col(images, patches, v.patch_size)
+        return patches
+
+
+class GeneTransformerTower(PatchTransformerTower):
+    """BASELINE configs[4]'s gene transformer (no reference symbol; model_configs.GeneCfg kind="transformer"): fills the
+    ``texts`` slot of the batch with a float [B, n_genes] matrix like the gene-MLP tower."""
+
+    prefix = "gene."
+
+    def __init__(self, cfg: ModelCfg, store: ParamStore):
+        g = cfg.gene
+        self.g = g
+        if g.patch % 64:
+            raise ValueError(f"gene patch size {g.patch} must be a multiple of 64")
+        super().__init__(cfg, store, g.width, g.heads, g.layers, g.mlp_ratio, g.tokens, g.patch)
+
+    def param_names(self) -> List[str]:
+        return [n for n in self.s.by_name if n.startswith("gene.")]
+
+    def _patchify(self, x: torch.Tensor) -> torch.Tensor:
+        g = self.g
+        if x.dim() != 2 or x.shape[1] != g.n_genes:
+            raise ValueError(f"gene matrix must be [B,{g.n_genes}], got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        self.B = B = x.shape[0]
+        T = self.L - 1
+        patches = self.bufs.get("patches", (B * T, g.patch), BF16)
+        # one cast pass: row b of the padded [B, T * patch] matrix IS rows b*T .. b*T+T-1 of the patch operand
+        ops.cast_pad_bf16(x, patches.view(B, T * g.patch), B, g.n_genes, T * g.patch)
+        return patches
 
 
 class GeneTower:

@@ -191,3 +191,27 @@ def test_checkpoint_prefixes_and_step_output_contract():
     assert net.strip_checkpoint_prefix("transformer.resblocks.0.ln_1.weight") == "transformer.resblocks.0.ln_1.weight"
     out = module.StepOutput({"loss": 1.0, "image_features": None})
     assert "logits" in out and set(out.keys()) >= {"loss", "logits", "image_features"}     # spatial_clip_module.py:70
+
+
+def test_gene_transformer_registry_and_parameter_layout():
+    """BASELINE configs[4]: ``ViT-L-14-genetr`` = ViT-L/14 image tower + 6-layer gene transformer; the product's flat
+    parameter layout and the oracle's init agree on every name and shape."""
+    cfg = mc.get_model_config("ViT-L-14-genetr", 20000)
+    g = cfg.gene
+    assert (g.kind, g.layers, g.width, g.patch, g.tokens, g.heads) == ("transformer", 6, 512, 256, 80, 8)
+    assert cfg.vision.width == 1024 and cfg.vision.layers == 24 and cfg.embed_dim == 768 and cfg.text is None
+    small = mc.ModelCfg(32, mc.VisionCfg(32, 8, 64, 2, 32), None, mc.GeneCfg(300, 0, "transformer", 64, 64, 2, 32))
+    specs = {s.name: tuple(s.shape) for s in params.build_specs(small)}
+    ocfg = O.ModelCfg(32, O.VisionCfg(32, 8, 64, 2, 32), None, O.GeneCfg(300, 0, "transformer", 64, 64, 2, 32))
+    op = O.init_params(ocfg, 0)
+    assert specs == {k: tuple(v.shape) for k, v in op.items()}
+    names = [s.name for s in params.build_specs(small)]
+    assert names.index("gene.conv1.weight") > names.index("visual.proj") and names[-1] == "logit_scale"
+    # the oracle tower: unit-norm output, finite gradients for every gene parameter, padding genes are inert
+    x = torch.rand(3, 300)
+    p = {k: v.clone().requires_grad_(True) for k, v in op.items()}
+    f = O.encode_gene_transformer(x, p, ocfg)
+    assert torch.allclose(f.norm(dim=1), torch.ones(3), atol=1e-5)
+    f.sum().backward()
+    assert all(torch.isfinite(p[k].grad).all() and p[k].grad.abs().sum() > 0 for k in p if k.startswith("gene."))
+    assert float(p["gene.conv1.weight"].grad.abs().sum()) > 0

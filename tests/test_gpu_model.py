@@ -348,3 +348,86 @@ def test_pretrained_file_with_other_grid_is_resized(tmp_path):
             assert torch.equal(sa[k].cpu(), sb[k].cpu()), k
     out = b(torch.randn(4, 3, 48, 48).cuda(), torch.randn(4, cfg_b.gene.n_genes).cuda())
     assert torch.isfinite(out["image_features"]).all()
+
+
+# ---------------------------------------------------------------------------------------------------- gene transformer
+def genetr_cfgs(width=64, head_width=32, layers=2, image=32, patch=8, embed=32, n_genes=300, gpatch=64, gwidth=64,
+                glayers=2, ghead=32):
+    """BASELINE configs[4]'s second tower at test size: 1-D patch transformer over the expression vector."""
+    _, _, mc, _, _, _ = _pkg()
+    cfg = mc.ModelCfg(embed_dim=embed, vision=mc.VisionCfg(image, patch, width, layers, head_width), text=None,
+                      gene=mc.GeneCfg(n_genes, 0, "transformer", gpatch, gwidth, glayers, ghead))
+    ocfg = O.ModelCfg(embed_dim=embed, vision=O.VisionCfg(image, patch, width, layers, head_width), text=None,
+                      gene=O.GeneCfg(n_genes, 0, "transformer", gpatch, gwidth, glayers, ghead))
+    return cfg, ocfg
+
+
+@pytest.mark.parametrize("gwidth,ghead,n_genes", [(64, 32, 300), (128, 64, 1000)])
+def test_gene_transformer_forward_backward_vs_oracle(gwidth, ghead, n_genes):
+    data, losses, mc, module, net, optim = _pkg()
+    cfg, ocfg = genetr_cfgs(n_genes=n_genes, gwidth=gwidth, ghead=ghead, glayers=3)
+    assert cfg.gene.tokens == (n_genes + 63) // 64 + 1
+    B = 12
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=4)
+    perturb(n)
+    params = {k: v.cpu() for k, v in n.state_dict().items()}
+    assert set(params) == set(O.init_params(ocfg, 0)), "oracle / product parameter names disagree"
+    batch = data.synthetic_batch(B, 32, n_genes, K=4, step=0)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f = O.net_forward(batch["images"], batch["texts"], p, ocfg)
+    lo = O.spatial_loss(f["image_features"], f["text_features"], f["logit_scale"], batch["image_tile_ids"],
+                        batch["text_tile_ids"], batch["neighbor_tile_ids"], batch["neighbor_alphas"])
+    lo.backward()
+    loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                 neighbor_alpha_scale=0.5, float32_logits=True)
+    m = module.SpatialClipLitModule(n, loss_fn, None, None)
+    out = m.model_step({k: v.cuda() for k, v in batch.items()})
+    assert (out["text_features"].cpu() - f["text_features"].detach()).abs().max() < 5e-3
+    assert (out["image_features"].cpu() - f["image_features"].detach()).abs().max() < 5e-3
+    assert abs(float(out["loss"].detach()) - float(lo.detach())) < 4e-3
+    raw = n.model.encode_text(batch["texts"].cuda(), normalize=False).cpu()          # pre-normalisation features
+    torch.testing.assert_close(raw, O.encode_gene_transformer(batch["texts"], params, ocfg, normalize=False),
+                               atol=3e-2, rtol=3e-2)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    bad = []
+    for k in params:
+        g_ref = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
+        g = n.store.g(k).cpu()
+        tol = 0.03 * float(g_ref.abs().max()) + 1e-6
+        if float((g - g_ref).abs().max()) > tol:
+            bad.append((k, float((g - g_ref).abs().max()), float(g_ref.abs().max())))
+    assert not bad, bad
+
+
+def test_gene_transformer_three_training_steps_vs_oracle():
+    data, losses, mc, module, net, optim = _pkg()
+    import functools
+    cfg, ocfg = genetr_cfgs()
+    B = 16
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=6)
+    perturb(n)
+    params = {k: v.cpu() for k, v in n.state_dict().items()}
+    loss_fn = losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True)
+    m = module.SpatialClipLitModule(
+        n, loss_fn, functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=2))
+
+    class T:
+        max_steps, max_epochs, estimated_stepping_batches = 10, None, 10
+    m.trainer = T()
+    oc = m.configure_optimizers()
+    opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+    tr = O.OracleTrainer(ocfg, params, loss="clip", lr=1e-3, warmup=2, total_steps=10)
+    for step in range(3):
+        batch = data.synthetic_batch(B, 32, cfg.gene.n_genes, K=4, step=step)
+        ref = tr.training_step(batch)
+        loss = m.training_step({k: v.cuda() for k, v in batch.items()}, step)
+        loss.backward()
+        nc = opt.step(grad_scale=1.0, max_norm=1.0)
+        sched.step()
+        assert abs(float(loss.detach()) - float(ref["loss"])) < 4e-3, (step, float(loss.detach()), float(ref["loss"]))
+        assert abs(float(nc[0]) - float(ref["grad_norm"])) < 0.03 * float(ref["grad_norm"]) + 1e-4
+    for k in ("gene.proj", "gene.conv1.weight", "gene.transformer.resblocks.1.mlp.c_fc.weight", "gene.positional_embedding"):
+        a, b = n.store.p(k).cpu(), tr.p[k].detach()
+        assert float((a - b).abs().max()) < 2.5e-3, k
