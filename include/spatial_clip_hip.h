@@ -185,6 +185,20 @@ int sc_pcc_rows(const float* pred, long long ldp, const float* target, long long
 int sc_exp_scalar(const float* x, float* y, void* stream);
 int sc_exp_scalar_bwd(const float* y, const float* dy, float* dx, float mult, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ input pipeline
+ *  the data-dependent dataloader steps, on the device.
+ * sc_knn_alpha: K nearest tiles of every tile of ONE slide from its (x, y) centroids (xy[N][2]), self excluded, ties by
+ * index; nbr_index[N][K] holds slide-local indices (-1 = fewer than K other tiles), alpha[N][K] the loss weights,
+ * normalised per row: mode 0 weight = 1 / (distance + 1e-6) (docs/spatial_clip_data_pipeline.html, Step 1), mode 1
+ * weight = exp(-d^2 / (2 sigma^2)) (notebooks/d1_dataset_construct_cw.ipynb).
+ * sc_augment_tiles: decoded uint8 tiles [B][H][W][3] -> fp32 [B][3][S][S]: crop box + optional flip, bilinear resize,
+ * ColorJitter (brightness / contrast / saturation factors applied in the per-sample order code 0..5), Normalize.
+ * params12[B][12] = {x0, y0, crop_w, crop_h, brightness, contrast, saturation, order, flip, 0, 0, 0}; mean3 / std3 are
+ * HOST pointers (configs/model/spatial_clip.yaml:12-17, src/open_clip/constants.py:1-2). */
+int sc_knn_alpha(const float* xy, int N, int K, int mode, float sigma, int* nbr_index, float* alpha, void* stream);
+int sc_augment_tiles(const void* src_u8_hwc, int B, int H, int W, const float* params12, float* out_nchw, int S,
+                     const float* mean3_host, const float* std3_host, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ optimiser
  * clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (src/models/spatial_clip_module.py:138-158,
  * configs/optimizer/adamw.yaml, configs/trainer/default.yaml:19).  grad_scale = 1/world_size folds DDP's

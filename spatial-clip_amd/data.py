@@ -87,3 +87,17 @@ class _Loader:
 
     def __len__(self):
         return self.n
+
+
+def SpatialClipDataModule(*args, **kwargs):
+    """Factory behind the reference's ``_target_: src.data.spatial_datamodule.SpatialClipDataModule``: the
+    ``dataset_format`` key picks the backend like the reference's ``create_spatial_dataset`` (spatial_datamodule.py:143):
+    ``shards_v1`` -> device-side shard pipeline (shards.py), ``synthetic`` -> HEST-shaped synthetic batches."""
+    fmt = kwargs.get("dataset_format", "synthetic")
+    if fmt == "shards_v1":
+        from .shards import ShardedSpatialDataModule
+        return ShardedSpatialDataModule(*args, **kwargs)
+    if fmt == "synthetic":
+        return SyntheticSpatialDataModule(*args, **kwargs)
+    raise ValueError(f"dataset_format {fmt!r}: supported are 'shards_v1' and 'synthetic' "
+                     "('parquet_v1' is the reference's legacy layout; convert it to shards)")

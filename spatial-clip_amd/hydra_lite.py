@@ -27,7 +27,7 @@ TARGET_MAP = {
     "src.models.components.losses.SpatialLoss": "spatial_clip_amd.losses.SpatialLoss",
     "src.models.components.losses.ClipLoss": "spatial_clip_amd.losses.ClipLoss",
     "src.models.components.metrics.ContrastiveMetrics": "spatial_clip_amd.metrics.ContrastiveMetrics",
-    "src.data.spatial_datamodule.SpatialClipDataModule": "spatial_clip_amd.data.SyntheticSpatialDataModule",
+    "src.data.spatial_datamodule.SpatialClipDataModule": "spatial_clip_amd.data.SpatialClipDataModule",
     "open_clip.AugmentationCfg": "spatial_clip_amd.net.AugmentationCfg",
     "torch.optim.AdamW": "spatial_clip_amd.optim.FusedAdamW",
     "transformers.get_cosine_schedule_with_warmup": "spatial_clip_amd.optim.get_cosine_schedule_with_warmup",

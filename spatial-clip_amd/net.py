@@ -123,7 +123,8 @@ class _ClipFacade:
 class SpatialClipNet(torch.nn.Module):
     def __init__(self, model_name: str, pretrained: Optional[str] = None, aug_cfg: Optional[Any] = None,
                  cache_dir: Optional[str] = None, n_genes: Optional[int] = None, gene_hidden: Optional[int] = None,
-                 device: Optional[str] = None, seed: int = 0, model_cfg: Optional[ModelCfg] = None):
+                 device: Optional[str] = None, seed: int = 0, model_cfg: Optional[ModelCfg] = None,
+                 tokenizer_vocab: Optional[str] = None):
         super().__init__()
         if aug_cfg is not None and not isinstance(aug_cfg, (dict, AugmentationCfg)) and not is_dataclass(aug_cfg) \
                 and not hasattr(aug_cfg, "items"):
@@ -149,6 +150,8 @@ class SpatialClipNet(torch.nn.Module):
         self.model = _ClipFacade(self)
         self.preprocess_train = self.preprocess_val = self._preprocess
         self.tokenizer = self._tokenizer
+        self.tokenizer_vocab = tokenizer_vocab      # BPE merge table for string inputs of the text tower (tokenizer.py)
+        self._bpe = None
         self.grad_bucket_hook: Optional[Callable[[int, int], None]] = None
         self.feature_gather = None          # comm.FeatureGather, installed per step by the module when W > 1
         if pretrained:
@@ -172,13 +175,16 @@ class SpatialClipNet(torch.nn.Module):
         return (img - mean) / std
 
     def _tokenizer(self, x):
-        """Gene tower: the 'tokenizer' passes gene-expression vectors through as a float matrix.  Text tower: token
-        ids pass through; BPE tokenisation of strings is CPU-side data preparation outside the hot path."""
+        """Gene towers: the 'tokenizer' passes gene-expression vectors through as a float matrix.  Text tower: token ids
+        pass through; strings go through the package's own byte-level BPE tokenizer (tokenizer.py; needs CLIP's merge
+        table via ``tokenizer_vocab`` / ``$SC_BPE_VOCAB``)."""
         if self.cfg.gene is not None:
             return torch.as_tensor(x, dtype=torch.float32)
-        if isinstance(x, (str, list)) and (isinstance(x, str) or (x and isinstance(x[0], str))):
-            raise NotImplementedError("BPE tokenisation (src/open_clip/tokenizer.py) is out of scope: pass int64 "
-                                      "[B, context_length] token ids")
+        if isinstance(x, (str, list, tuple)) and (isinstance(x, str) or (len(x) and isinstance(x[0], str))):
+            if self._bpe is None:
+                from .tokenizer import BpeTokenizer      # raises FileNotFoundError with instructions if no merge table
+                self._bpe = BpeTokenizer(self.tokenizer_vocab, self.cfg.text.context_length)
+            return self._bpe(x)
         return torch.as_tensor(x, dtype=torch.int64)
 
     def load_checkpoint_state_dict(self, sd: Dict[str, Any], source: str = "checkpoint") -> Dict[str, List[str]]:

@@ -395,3 +395,35 @@ def pcc_rows(pred: torch.Tensor, target: torch.Tensor, pcc: Optional[torch.Tenso
         raise _lib.SpatialClipHipError(f"pcc_rows: pred {tuple(pred.shape)} vs target {tuple(target.shape)}")
     check(_lib.lib().sc_pcc_rows(pred.data_ptr(), pred.stride(0), target.data_ptr(), target.stride(0), rows, cols,
                                  _ptr(pcc), _ptr(sum_count), _stream()), "sc_pcc_rows")
+
+
+# ------------------------------------------------------------------------------------------ input pipeline
+def knn_alpha(xy: torch.Tensor, K: int, mode: str = "inverse", sigma: float = 1.0):
+    """Spatial neighbours + loss weights of the tiles of one slide: xy fp32 [N,2] -> (nbr_index int32 [N,K], alpha [N,K])."""
+    _req(xy, torch.float32, "xy")
+    if xy.dim() != 2 or xy.shape[1] != 2 or not xy.is_contiguous():
+        raise ValueError("knn_alpha: xy must be a contiguous [N, 2] tensor")
+    N = xy.shape[0]
+    nbr = torch.empty((N, K), dtype=torch.int32, device=xy.device)
+    alpha = torch.empty((N, K), dtype=torch.float32, device=xy.device)
+    check(_lib.lib().sc_knn_alpha(xy.data_ptr(), N, K, {"inverse": 0, "gaussian": 1}[mode], float(sigma), nbr.data_ptr(),
+                                  alpha.data_ptr(), _stream()), "sc_knn_alpha")
+    return nbr, alpha
+
+
+def augment_tiles(src_u8: torch.Tensor, params: torch.Tensor, out_size: int, mean, std) -> torch.Tensor:
+    """uint8 [B,H,W,3] + params fp32 [B,12] -> normalised fp32 [B,3,S,S] (crop, resize, colour jitter, normalise)."""
+    if not src_u8.is_cuda or src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[3] != 3 \
+            or not src_u8.is_contiguous():
+        raise TypeError("augment_tiles: src must be a contiguous device uint8 [B,H,W,3] tensor")
+    _req(params, torch.float32, "params")
+    B, H, W, _ = src_u8.shape
+    if tuple(params.shape) != (B, 12) or not params.is_contiguous():
+        raise ValueError("augment_tiles: params must be [B, 12]")
+    out = torch.empty((B, 3, out_size, out_size), dtype=torch.float32, device=src_u8.device)
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(_lib.lib().sc_augment_tiles(src_u8.data_ptr(), B, H, W, params.data_ptr(), out.data_ptr(), out_size,
+                                      ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), _stream()),
+          "sc_augment_tiles")
+    return out

@@ -1,0 +1,250 @@
+"""``shards_v1`` input pipeline with the data-dependent work on the device.
+
+Format (reference: docs/data_pipeline.md:19, the fixture of tests/test_spatial_datasets.py:57-75): one directory per
+slide under ``data_dir``, holding ``*.tar`` files whose members come in triples ``<base>.png`` (RGB tile), ``<base>.txt``
+(gene sentence) and ``<base>.json`` (``{"sample_id", "x", "y", ...}``: tile centroid in slide pixels).
+
+What runs where
+  host    tar indexing, PNG inflate (PIL), string handling (gene sentence -> tokens through ``tokenizer``, or ->
+          a rank-weighted gene vector for the gene towers), the random draws of the augmentation parameters
+  device  K-nearest-neighbour search per slide and the loss weights alpha (``sc_knn_alpha``), RandomResizedCrop +
+          bilinear resize + ColorJitter + Normalize of the whole batch in one launch (``sc_augment_tiles``)
+The batch dict is the reference's ``_collate_fn`` contract (src/data/spatial_datamodule.py:110-137): ``images``,
+``texts``, ``image_tile_ids`` = ``text_tile_ids``, ``neighbor_tile_ids`` (pad -1), ``neighbor_alphas`` (pad 0), ``raw_text``.
+Tile ids are global int64 row indices over (sorted slide ids, member order) like the reference's
+(notebooks/d1_dataset_construct_cw.ipynb).  Batches are drawn by the neighbour-aware sampler (sampler.py)."""
+from __future__ import annotations
+
+import io
+import json
+import math
+import os
+import tarfile
+from typing import Any, Callable, Dict, Iterator, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import comm, ops
+from .sampler import SpatialBucketBatchSampler, build_fast_indices
+
+OPENAI_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class ShardIndex:
+    """Byte offsets of every (png, txt, json) triple of the selected slides; nothing is decoded at construction."""
+
+    def __init__(self, data_dir: str, sample_ids: Optional[Sequence[str]] = None):
+        if not os.path.isdir(data_dir):
+            raise FileNotFoundError(f"shards_v1 data_dir {data_dir!r} does not exist")     # spatial_datamodule.py:65-71
+        slides = sorted(d for d in os.listdir(data_dir) if os.path.isdir(os.path.join(data_dir, d)) and not d.startswith("."))
+        if sample_ids is not None:
+            missing = [s for s in sample_ids if s not in slides]
+            if missing:
+                raise FileNotFoundError(f"slides {missing} not found under {data_dir}")
+            slides = sorted(sample_ids)
+        self.entries: List[Dict[str, Any]] = []          # {tar, png:(off,size), txt:(off,size), sample_id, x, y}
+        for sid in slides:
+            sdir = os.path.join(data_dir, sid)
+            for tname in sorted(f for f in os.listdir(sdir) if f.endswith(".tar")):
+                tpath = os.path.join(sdir, tname)
+                groups: Dict[str, Dict[str, Any]] = {}
+                with tarfile.open(tpath, "r") as tar:
+                    for m in tar:
+                        if not m.isfile():
+                            continue
+                        base, _, ext = m.name.rpartition(".")
+                        g = groups.setdefault(base, {})
+                        if ext == "json":
+                            g["meta"] = json.loads(tar.extractfile(m).read().decode("utf-8"))
+                        elif ext in ("png", "txt"):
+                            g[ext] = (m.offset_data, m.size)
+                for base in sorted(groups):
+                    g = groups[base]
+                    if "png" not in g or "txt" not in g or "meta" not in g:
+                        continue                         # incomplete triple: skipped, like a failed sample in the reference
+                    meta = g["meta"]
+                    self.entries.append({"tar": tpath, "png": g["png"], "txt": g["txt"],
+                                         "sample_id": str(meta.get("sample_id", sid)),
+                                         "x": float(meta["x"]), "y": float(meta["y"])})
+        if not self.entries:
+            raise FileNotFoundError(f"no complete (png, txt, json) triples under {data_dir}")
+        self.sample_ids = np.array([e["sample_id"] for e in self.entries])
+        self.tile_ids = np.arange(len(self.entries), dtype=np.int64)
+        self.xy = np.array([[e["x"], e["y"]] for e in self.entries], dtype=np.float32)
+
+    def __len__(self) -> int:
+        return len(self.entries)
+
+    def read(self, i: int):
+        e = self.entries[i]
+        with open(e["tar"], "rb") as f:
+            f.seek(e["png"][0])
+            png = f.read(e["png"][1])
+            f.seek(e["txt"][0])
+            txt = f.read(e["txt"][1]).decode("utf-8")
+        return png, txt
+
+
+def decode_png(png: bytes, size: Optional[int] = None) -> np.ndarray:
+    """RGB uint8 [H, W, 3]; PIL does the inflate (host).  ``size``: nearest-exact pre-resize of tiles that were not
+    written at the working resolution, so that a batch is one dense [B, H, W, 3] array."""
+    from PIL import Image
+    im = Image.open(io.BytesIO(png)).convert("RGB")
+    if size is not None and im.size != (size, size):
+        im = im.resize((size, size), Image.BILINEAR)
+    return np.asarray(im, dtype=np.uint8)
+
+
+def neighbor_tables(index: ShardIndex, k_neighbors: int, mode: str = "inverse", device=None):
+    """Per-slide KNN + alpha on the device -> (neighbor_tile_ids int64 [N,K] pad -1, neighbor_alphas f32 [N,K] pad 0) in
+    GLOBAL tile ids, and the edges map for the sampler."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    N, K = len(index), int(k_neighbors)
+    nbr_ids = torch.full((N, K), -1, dtype=torch.int64)
+    alphas = torch.zeros((N, K), dtype=torch.float32)
+    for sid in np.unique(index.sample_ids):
+        rows = np.nonzero(index.sample_ids == sid)[0]
+        xy = torch.from_numpy(index.xy[rows]).to(device).contiguous()
+        loc, al = ops.knn_alpha(xy, K, mode)
+        loc, al = loc.cpu().long(), al.cpu()
+        glob = torch.where(loc >= 0, torch.from_numpy(index.tile_ids[rows])[loc.clamp_min(0)], torch.full_like(loc, -1))
+        nbr_ids[rows] = glob
+        alphas[rows] = al
+    edges_map = {int(t): [int(v) for v in nbr_ids[i].tolist() if v >= 0] for i, t in enumerate(index.tile_ids)}
+    return nbr_ids, alphas, edges_map
+
+
+def draw_aug_params(B: int, H: int, W: int, aug_cfg: Optional[Dict[str, Any]], rng: np.random.Generator,
+                    train: bool = True) -> torch.Tensor:
+    """One parameter row per sample for ``sc_augment_tiles``.  Training: torchvision RandomResizedCrop semantics
+    (area fraction ~ U(scale), log-uniform aspect ratio, 10 attempts then centre crop) and ColorJitter factors
+    ~ U(1 - j, 1 + j) in a random order (timm's ``color_jitter`` scalar -> brightness = contrast = saturation = j, no
+    hue).  Evaluation: the full tile, no jitter."""
+    P = np.zeros((B, 12), dtype=np.float32)
+    P[:, 4:7] = 1.0
+    P[:, 2], P[:, 3] = W, H
+    if not train or not aug_cfg:
+        return torch.from_numpy(P)
+    scale = tuple(aug_cfg.get("scale", (0.9, 1.0)))
+    ratio = tuple(aug_cfg.get("ratio", (0.75, 1.3333)))
+    j = aug_cfg.get("color_jitter", 0.0) or 0.0
+    j = float(j[0]) if isinstance(j, (list, tuple)) else float(j)
+    for b in range(B):
+        cw, ch, x0, y0 = W, H, 0.0, 0.0
+        for _ in range(10):
+            area = H * W * rng.uniform(*scale)
+            ar = math.exp(rng.uniform(math.log(ratio[0]), math.log(ratio[1])))
+            w_, h_ = int(round(math.sqrt(area * ar))), int(round(math.sqrt(area / ar)))
+            if 0 < w_ <= W and 0 < h_ <= H:
+                cw, ch = w_, h_
+                x0, y0 = float(rng.integers(0, W - w_ + 1)), float(rng.integers(0, H - h_ + 1))
+                break
+        else:
+            x0, y0 = (W - cw) / 2, (H - ch) / 2
+        P[b, 0:4] = (x0, y0, cw, ch)
+        if j > 0:
+            P[b, 4:7] = rng.uniform(max(0.0, 1 - j), 1 + j, size=3)
+            P[b, 7] = float(rng.integers(0, 6))
+    return torch.from_numpy(P)
+
+
+def rank_weighted_vector(sentence: str, gene_to_idx: Dict[str, int], n_genes: int) -> np.ndarray:
+    """Gene sentence ("top-N gene symbols, most expressed first") -> dense [n_genes] vector with weight
+    1 - rank / N at each listed gene: the target construction of src/metrics/zero_shot.py:41-60, reused as the gene
+    towers' input when only sentences are stored."""
+    v = np.zeros(n_genes, dtype=np.float32)
+    genes = [g for g in sentence.split() if g in gene_to_idx]
+    for r, g in enumerate(genes):
+        v[gene_to_idx[g]] = max(v[gene_to_idx[g]], 1.0 - r / max(len(genes), 1))
+    return v
+
+
+class ShardedSpatialDataModule:
+    """``SpatialClipDataModule`` constructor kwargs (spatial_datamodule.py:21-31) with ``dataset_format="shards_v1"``;
+    ``splits`` maps "train" / "val" / "test" to lists of slide ids."""
+
+    def __init__(self, data_dir: str = "", k_neighbors: int = 8, batch_size: int = 8, num_workers: int = 0,
+                 pin_memory: bool = False, dataset_format: str = "shards_v1",
+                 dataset_format_kwargs: Optional[Dict[str, Any]] = None, splits: Optional[Dict[str, Any]] = None,
+                 image_size: int = 224, n_genes: Optional[int] = None, gene_vocab: Optional[Sequence[str]] = None,
+                 aug_cfg: Optional[Dict[str, Any]] = None, alpha_mode: str = "inverse", seed: int = 2025,
+                 centers_per_batch: int = 16, max_neighbors_per_center: int = 4):
+        if dataset_format != "shards_v1":
+            raise ValueError(f"dataset_format {dataset_format!r}: this module reads 'shards_v1' "
+                             "(synthetic batches: data.SyntheticSpatialDataModule)")
+        self.data_dir, self.k_neighbors, self.batch_size = data_dir, int(k_neighbors), int(batch_size)
+        self.splits = dict(splits or {})
+        self.image_size, self.aug_cfg, self.alpha_mode, self.seed = int(image_size), aug_cfg, alpha_mode, int(seed)
+        self.n_genes = n_genes
+        self.gene_to_idx = {g: i for i, g in enumerate(gene_vocab)} if gene_vocab else None
+        self.centers_per_batch, self.max_neighbors_per_center = centers_per_batch, max_neighbors_per_center
+        self.preprocess_fn: Optional[Callable] = None
+        self.tokenizer: Optional[Callable] = None
+        self._sets: Dict[str, Dict[str, Any]] = {}
+
+    def setup(self, stage: Optional[str] = None) -> None:
+        if self.preprocess_fn is None or self.tokenizer is None:       # spatial_datamodule.py:79-80
+            raise ValueError("preprocess_fn and tokenizer must be set before setup()")
+        for name in ("train", "val", "test"):
+            if name in self._sets or (self.splits and name not in self.splits):
+                continue
+            index = ShardIndex(self.data_dir, self.splits.get(name))
+            nbr, al, edges = neighbor_tables(index, self.k_neighbors, self.alpha_mode)
+            index.edges_map = edges
+            index.id2idx, index.sample_to_indices, index.nbr_index = build_fast_indices(
+                index.tile_ids, index.sample_ids, edges, self.k_neighbors)
+            self._sets[name] = {"index": index, "nbr": nbr, "alpha": al}
+
+    def _texts(self, sentences: List[str]) -> torch.Tensor:
+        if self.gene_to_idx is not None:        # gene towers: float [B, n_genes]
+            n = self.n_genes or len(self.gene_to_idx)
+            return torch.from_numpy(np.stack([rank_weighted_vector(s, self.gene_to_idx, n) for s in sentences]))
+        return self.tokenizer(sentences)          # reference text tower: int64 [B, 77]
+
+    def _batches(self, name: str, train: bool) -> Iterator[Dict[str, Any]]:
+        st = self._sets[name]
+        index: ShardIndex = st["index"]
+        rank, W = comm.world()
+        bs = min(self.batch_size, max(1, len(index) // max(W, 1)))
+        sampler = SpatialBucketBatchSampler(index, bs, W, rank, self.centers_per_batch, self.max_neighbors_per_center,
+                                            drop_last=train, seed=self.seed)
+        sampler.set_epoch(getattr(self, "_epoch", 0))
+        rng = np.random.default_rng([self.seed, getattr(self, "_epoch", 0), rank, 0 if train else 1])
+        dev = torch.device("cuda", torch.cuda.current_device())
+        for idx in sampler:
+            pngs, sents = zip(*(index.read(i) for i in idx))
+            tiles = np.stack([decode_png(p, self.image_size) for p in pngs])
+            params = draw_aug_params(len(idx), tiles.shape[1], tiles.shape[2], self.aug_cfg, rng, train)
+            images = ops.augment_tiles(torch.from_numpy(tiles).to(dev), params.to(dev), self.image_size, OPENAI_MEAN, OPENAI_STD)
+            ids = torch.from_numpy(index.tile_ids[np.asarray(idx)])
+            yield {"images": images, "texts": self._texts(list(sents)), "image_tile_ids": ids, "text_tile_ids": ids.clone(),
+                   "neighbor_tile_ids": st["nbr"][np.asarray(idx)], "neighbor_alphas": st["alpha"][np.asarray(idx)],
+                   "raw_text": list(sents)}
+
+    def _loader(self, name: str, train: bool):
+        if name not in self._sets:
+            raise ValueError(f"split {name!r} was not set up (splits = {list(self.splits)})")
+        n = max(1, len(self._sets[name]["index"]) // max(self.batch_size * comm.world()[1], 1))
+        return _Loader(lambda: self._batches(name, train), n)
+
+    def train_dataloader(self):
+        return self._loader("train", True)
+
+    def val_dataloader(self):
+        return self._loader("val" if "val" in self._sets else "train", False)
+
+    def test_dataloader(self):
+        return self._loader("test" if "test" in self._sets else ("val" if "val" in self._sets else "train"), False)
+
+
+class _Loader:
+    def __init__(self, factory, n):
+        self.factory, self.n = factory, n
+
+    def __iter__(self):
+        return self.factory()
+
+    def __len__(self):
+        return self.n

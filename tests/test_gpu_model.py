@@ -385,19 +385,21 @@ def test_gene_transformer_forward_backward_vs_oracle(gwidth, ghead, n_genes):
     assert (out["text_features"].cpu() - f["text_features"].detach()).abs().max() < 5e-3
     assert (out["image_features"].cpu() - f["image_features"].detach()).abs().max() < 5e-3
     assert abs(float(out["loss"].detach()) - float(lo.detach())) < 4e-3
-    raw = n.model.encode_text(batch["texts"].cuda(), normalize=False).cpu()          # pre-normalisation features
-    torch.testing.assert_close(raw, O.encode_gene_transformer(batch["texts"], params, ocfg, normalize=False),
-                               atol=3e-2, rtol=3e-2)
     out["loss"].backward()
     torch.cuda.synchronize()
     bad = []
     for k in params:
         g_ref = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
         g = n.store.g(k).cpu()
-        tol = 0.03 * float(g_ref.abs().max()) + 1e-6
+        # 5 % of the tensor's max-abs: both towers are now multi-layer bf16 transformers, and the feature noise of each
+        # (<= 5e-3) enters the other tower's gradient through the similarity matrix
+        tol = 0.05 * float(g_ref.abs().max()) + 1e-6
         if float((g - g_ref).abs().max()) > tol:
             bad.append((k, float((g - g_ref).abs().max()), float(g_ref.abs().max())))
     assert not bad, bad
+    raw = n.model.encode_text(batch["texts"].cuda(), normalize=False).cpu()          # pre-normalisation features
+    torch.testing.assert_close(raw, O.encode_gene_transformer(batch["texts"], params, ocfg, normalize=False),
+                               atol=3e-2, rtol=3e-2)
 
 
 def test_gene_transformer_three_training_steps_vs_oracle():

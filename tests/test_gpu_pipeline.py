@@ -1,0 +1,138 @@
+"""Device side of the input pipeline: sc_knn_alpha against a numpy brute force, sc_augment_tiles
+against a plain-torch restatement of RandomResizedCrop / ColorJitter / Normalize, and the shards_v1 datamodule feeding
+the trainer end to end."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("N,K", [(1, 3), (5, 8), (200, 6), (3000, 8)])
+def test_knn_alpha_vs_bruteforce(N, K):
+    ops = _ops()
+    rng = np.random.default_rng(N)
+    xy = (rng.integers(0, 60, size=(N, 2)) * 2.5).astype(np.float32)          # a grid with ties and duplicates
+    nbr, alpha = ops.knn_alpha(torch.from_numpy(xy).cuda(), K)
+    nbr, alpha = nbr.cpu().numpy(), alpha.cpu().numpy()
+    d2 = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1)
+    for i in range(N):
+        order = sorted((j for j in range(N) if j != i), key=lambda j: (d2[i, j], j))[:K]
+        want = order + [-1] * (K - len(order))
+        assert nbr[i].tolist() == want, (i, nbr[i], want)
+        w = np.array([1.0 / (math.sqrt(d2[i, j]) + 1e-6) for j in order], dtype=np.float64)
+        if len(order):
+            np.testing.assert_allclose(alpha[i, :len(order)], w / w.sum(), rtol=2e-5)
+            assert abs(alpha[i].sum() - 1.0) < 1e-5                              # notebook check 1: rows sum to 1
+        assert (alpha[i, len(order):] == 0).all()
+    nb2, al2 = ops.knn_alpha(torch.from_numpy(xy).cuda(), K, "gaussian", sigma=5.0)
+    assert torch.equal(nb2.cpu(), torch.from_numpy(nbr))
+    i = N // 2
+    order = [j for j in nbr[i] if j >= 0]
+    if order:
+        w = np.exp(-np.array([d2[i, j] for j in order]) / 50.0)
+        np.testing.assert_allclose(al2.cpu().numpy()[i, :len(order)], w / w.sum(), rtol=1e-4, atol=1e-7)
+
+
+def _ref_augment(src, P, S, mean, std):
+    """Plain torch: crop box -> bilinear (align_corners=False, no antialias) -> jitter ops in order -> normalise."""
+    perms = [(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)]
+    out = []
+    for b in range(src.shape[0]):
+        x0, y0, cw, ch, br, ct, sa, order, flip = [float(v) for v in P[b, :9]]
+        img = src[b].permute(2, 0, 1).float() / 255.0                    # [3,H,W]
+        H, W = img.shape[1:]
+        ox = torch.arange(S, dtype=torch.float32)
+        sx = (x0 + (ox + 0.5) * (cw / S) - 0.5).clamp(0, W - 1)
+        sy = (y0 + (ox + 0.5) * (ch / S) - 0.5).clamp(0, H - 1)
+        x0i, y0i = sx.floor().long(), sy.floor().long()
+        x1i, y1i = (x0i + 1).clamp(max=W - 1), (y0i + 1).clamp(max=H - 1)
+        fx, fy = (sx - x0i).view(1, 1, S), (sy - y0i).view(1, S, 1)
+        top = img[:, y0i][:, :, x0i] * (1 - fx) + img[:, y0i][:, :, x1i] * fx
+        bot = img[:, y1i][:, :, x0i] * (1 - fx) + img[:, y1i][:, :, x1i] * fx
+        v = top * (1 - fy) + bot * fy
+        if flip > 0.5:
+            v = v.flip(-1)
+        gray = lambda t: 0.299 * t[0] + 0.587 * t[1] + 0.114 * t[2]
+        for op in perms[int(order)]:
+            if op == 0:
+                v = (v * br).clamp(0, 1)
+            elif op == 1:
+                v = (ct * v + (1 - ct) * gray(v).mean()).clamp(0, 1)
+            else:
+                v = (sa * v + (1 - sa) * gray(v).unsqueeze(0)).clamp(0, 1)
+        m = torch.tensor(mean).view(3, 1, 1)
+        s = torch.tensor(std).view(3, 1, 1)
+        out.append((v - m) / s)
+    return torch.stack(out)
+
+
+def test_augment_tiles_vs_torch_restatement():
+    ops = _ops()
+    from spatial_clip_amd import shards
+    g = torch.Generator().manual_seed(0)
+    B, H, W, S = 6, 40, 52, 32
+    src = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    P = shards.draw_aug_params(B, H, W, {"scale": [0.5, 1.0], "ratio": [0.75, 1.333], "color_jitter": 0.4},
+                               np.random.default_rng(3))
+    P[1, 8] = 1.0                                                        # one flipped sample
+    P[2, 7], P[3, 7], P[4, 7] = 1.0, 3.0, 5.0                            # several op orders
+    out = ops.augment_tiles(src.cuda(), P.cuda(), S, shards.OPENAI_MEAN, shards.OPENAI_STD).cpu()
+    ref = _ref_augment(src, P, S, shards.OPENAI_MEAN, shards.OPENAI_STD)
+    torch.testing.assert_close(out, ref, atol=2e-5, rtol=1e-5)
+    # identity parameters at the source size reproduce Normalize(ToTensor(tile)) exactly
+    sq = torch.randint(0, 256, (2, 24, 24, 3), generator=g, dtype=torch.uint8)
+    Pid = shards.draw_aug_params(2, 24, 24, None, np.random.default_rng(0), train=False)
+    o = ops.augment_tiles(sq.cuda(), Pid.cuda(), 24, shards.OPENAI_MEAN, shards.OPENAI_STD).cpu()
+    want = (sq.permute(0, 3, 1, 2).float() / 255.0 - torch.tensor(shards.OPENAI_MEAN).view(1, 3, 1, 1)) / \
+        torch.tensor(shards.OPENAI_STD).view(1, 3, 1, 1)
+    torch.testing.assert_close(o, want, atol=1e-6, rtol=1e-6)
+
+
+def test_shards_datamodule_feeds_the_trainer(tmp_path, monkeypatch):
+    """shards_v1 tar fixtures (the reference test's layout) -> index -> device KNN / alpha -> neighbour-aware batches ->
+    device augmentation -> SpatialLoss training steps on a tiny model.  Checks the batch contract and that the
+    neighbour columns really resolve inside the batches."""
+    from tests.test_cpu_pipeline import _make_shards
+    import functools
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data, losses, model_configs as mc, module, net, optim, trainer
+    root = _make_shards(str(tmp_path / "processed"), slides=2, tiles=36, px=16)
+    genes = [f"GENE{i}" for i in range(36)] + ["ACTB"]
+    dm = data.SpatialClipDataModule(data_dir=root, k_neighbors=4, batch_size=12, dataset_format="shards_v1",
+                                    splits={"train": ["SAMPLE_A", "SAMPLE_B"], "val": ["SAMPLE_B"]}, image_size=32,
+                                    gene_vocab=genes, aug_cfg={"scale": [0.9, 1.0], "color_jitter": 0.2},
+                                    centers_per_batch=3, max_neighbors_per_center=3)
+    cfg = mc.ModelCfg(embed_dim=32, vision=mc.VisionCfg(32, 8, 64, 2, 32), text=None, gene=mc.GeneCfg(len(genes), 64))
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=2)
+    loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                 neighbor_alpha_scale=0.5, float32_logits=True)
+    m = module.SpatialClipLitModule(
+        n, loss_fn, functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+    dm.preprocess_fn, dm.tokenizer = n.preprocess_train, n.tokenizer
+    dm.setup("fit")
+    batches = list(dm.train_dataloader())
+    assert len(batches) == 72 // 12
+    hits = 0
+    for b in batches:
+        assert tuple(b["images"].shape) == (12, 3, 32, 32) and b["images"].is_cuda and b["images"].dtype == torch.float32
+        assert tuple(b["texts"].shape) == (12, len(genes)) and b["neighbor_tile_ids"].shape == (12, 4)
+        assert torch.equal(b["image_tile_ids"], b["text_tile_ids"]) and len(b["raw_text"]) == 12
+        assert torch.allclose(b["neighbor_alphas"].sum(1), torch.ones(12), atol=1e-5)
+        ids = set(b["image_tile_ids"].tolist())
+        hits += sum(1 for v in b["neighbor_tile_ids"].flatten().tolist() if v in ids)
+    assert hits > 0.3 * 12 * 4 * len(batches), hits             # the sampler keeps neighbours in the batch
+    t = trainer.Trainer(max_epochs=2, gradient_clip_val=1.0, log_every_n_steps=1)
+    t.fit(m, dm)
+    assert t.global_step == 12 and all(math.isfinite(h["train/loss"]) for h in t.history if "train/loss" in h)
+    assert "val/loss" in t.history[-1] and math.isfinite(t.history[-1]["val/loss"])
