@@ -107,7 +107,7 @@ def test_shards_datamodule_feeds_the_trainer(tmp_path, monkeypatch):
     import spatial_clip_amd  # noqa: F401
     from spatial_clip_amd import data, losses, model_configs as mc, module, net, optim, trainer
     root = _make_shards(str(tmp_path / "processed"), slides=2, tiles=36, px=16)
-    genes = [f"GENE{i}" for i in range(36)] + ["ACTB"]
+    genes = [f"GENE{i}" for i in range(36)] + ["ACTB", "B2M", "FTL", "MALAT1"]     # the gene-MLP GEMMs want n_genes % 4 == 0
     dm = data.SpatialClipDataModule(data_dir=root, k_neighbors=4, batch_size=12, dataset_format="shards_v1",
                                     splits={"train": ["SAMPLE_A", "SAMPLE_B"], "val": ["SAMPLE_B"]}, image_size=32,
                                     gene_vocab=genes, aug_cfg={"scale": [0.9, 1.0], "color_jitter": 0.2},
