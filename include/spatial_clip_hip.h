@@ -50,6 +50,18 @@ long long sc_gemm_wgrad_ws_floats(int M, int N, int K, int splitk);
 int sc_gemm_wgrad_bias(const void* dY, int lddy, const void* X, int ldx, int M, int N, int K, float* dW, int ldw,
                        float* dbias, int splitk, float* ws, void* stream);
 
+/* FP8 (OCP e4m3fn) forward GEMM of BASELINE configs[4] ("fp8 MFMA"; the reference has no fp8 path).  Recipe: every
+ * operand ROW (token activations; weight output channel) is scaled by s = 2^floor(log2(448 / amax(row))) when it is
+ * quantised (sc_quantize_rows_fp8 writes 1/s per row; fixed_scale > 0 skips the amax pass), the products accumulate in
+ * fp32 on the matrix cores (v_mfma_scale_f32_16x16x128_f8f6f4, block scale 1.0) and accumulator (m, n) is multiplied
+ * by a_scale_inv[m] * b_scale_inv[n] before the bf16 kernel's epilogue (SC_EPI_BF16 / _BIAS / F32_BIAS_RES / GELU_PAIR /
+ * F32).  NT only: C[M,N] = A8[M,K] . B8[N,K]^T, K % 128 == 0, lda / ldb in bytes (= elements), multiples of 16. */
+int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long ld_src, int rows, int cols, void* dst_fp8,
+                         long long ld_dst, float* scale_inv, float fixed_scale, void* stream);
+int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
+                const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2, const float* bias,
+                const float* res, int ldres, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ attention
  * Fused multi-head self-attention on the packed in_proj output qkv[B*L, 3*H*dh] (q | k | v, head h at
  * columns h*dh): softmax(q k^T / sqrt(dh)) v, fp32 softmax, optional causal mask.  Replaces

@@ -1,0 +1,104 @@
+// FP8 (OCP e4m3fn) forward path of the big linears -- BASELINE configs[4] "fp8 MFMA" (no reference counterpart: the
+// reference's only low-precision linear is the int8 bitsandbytes hook of its legacy loop, src/open_clip_train/main.py:259-271).
+//
+// Scaling recipe ("per-row, power-of-two, just in time"):
+//   * every ROW of an operand (a token's activation vector; an output channel's weight vector) gets its own scale
+//     s = 2^floor(log2(448 / amax(row)))  (448 = largest e4m3 value), so the stored row uses the top of the e4m3 range and
+//     the scale multiplication is exact in fp32;  amax = 0 -> s = 1;
+//   * scales are computed by the kernel that quantises the row (the whole row is in one wave) -- no amax history, no
+//     delayed scaling, nothing carried between steps;
+//   * the GEMM accumulates the raw e4m3 products in fp32 on the matrix cores (block scale 1.0) and multiplies
+//     accumulator (m, n) by a_scale_inv[m] * b_scale_inv[n] before bias / residual / GELU;
+//   * master weights stay fp32, the backward pass stays bf16 (weight and data gradients read the bf16 activations).
+#include "sc_gemm_common.h"
+
+namespace {
+
+SC_DEVICE unsigned pack4_fp8(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
+// one wave per row; cols % 8 == 0.  scale_inv[row] = 1 / s.
+template <bool F32>
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const void* __restrict__ src, long long ld_src, int rows, int cols,
+                                                            unsigned char* __restrict__ dst, long long ld_dst,
+                                                            float* __restrict__ scale_inv, float fixed_scale) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* sf = reinterpret_cast<const float*>(src) + (long long)row * ld_src;
+    const bf16* sb = reinterpret_cast<const bf16*>(src) + (long long)row * ld_src;
+    float s = fixed_scale;
+    if (!(fixed_scale > 0.f)) {
+        float amax = 0.f;
+        for (int c = lane * 8; c < cols; c += 512) {
+            if (F32) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sf + c), v1 = *reinterpret_cast<const f32x4*>(sf + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+            } else {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(sb + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[e]));
+            }
+        }
+        amax = sc_wave_max(amax);
+        s = amax > 0.f ? exp2f(floorf(log2f(448.0f / amax))) : 1.0f;
+    }
+    if (lane == 0 && scale_inv) scale_inv[row] = 1.0f / s;
+    unsigned char* d = dst + (long long)row * ld_dst;
+    for (int c = lane * 8; c < cols; c += 512) {
+        float v[8];
+        if (F32) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sf + c), v1 = *reinterpret_cast<const f32x4*>(sf + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+        } else {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(sb + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * s, -448.f), 448.f);
+        u32x2 o;
+        o[0] = pack4_fp8(v[0], v[1], v[2], v[3]);
+        o[1] = pack4_fp8(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<u32x2*>(d + c) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long ld_src, int rows, int cols, void* dst_fp8,
+                                    long long ld_dst, float* scale_inv, float fixed_scale, void* stream) {
+    SC_CHECK(rows > 0 && cols > 0 && (cols % 8) == 0 && ld_src >= cols && ld_dst >= cols && (ld_dst % 8) == 0,
+             "sc_quantize_rows_fp8: bad shape rows=%d cols=%d", rows, cols);
+    SC_CHECK((ld_src % (src_is_f32 ? 4 : 8)) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst_fp8 % 8) == 0,
+             "sc_quantize_rows_fp8: alignment");
+    const int blocks = (rows + 3) / 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (src_is_f32) quantize_rows_kernel<true><<<blocks, 256, 0, st>>>(src, ld_src, rows, cols, (unsigned char*)dst_fp8, ld_dst, scale_inv, fixed_scale);
+    else quantize_rows_kernel<false><<<blocks, 256, 0, st>>>(src, ld_src, rows, cols, (unsigned char*)dst_fp8, ld_dst, scale_inv, fixed_scale);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
+                           const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
+                           const float* bias, const float* res, int ldres, void* stream) {
+    SC_CHECK(M > 0 && N > 0 && K > 0 && (K % 128) == 0, "sc_gemm_fp8: K (%d) must be a positive multiple of 128", K);
+    SC_CHECK((lda % 16) == 0 && (ldb % 16) == 0 && ((uintptr_t)A8 % 16) == 0 && ((uintptr_t)B8 % 16) == 0,
+             "sc_gemm_fp8: operand rows must be 16-byte aligned (lda=%d ldb=%d)", lda, ldb);
+    const bool f32out = (epi == SC_EPI_F32 || epi == SC_EPI_F32_BIAS_RES);
+    SC_CHECK(epi != SC_EPI_BF16_DGELU, "sc_gemm_fp8: forward epilogues only");
+    SC_CHECK((N % (f32out ? 4 : 8)) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0, "sc_gemm_fp8: N=%d ldc=%d", N, ldc);
+    GemmArgs g;
+    g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
+    g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
+    g.aux = nullptr; g.ldaux = 0; g.colsum = nullptr; g.tile_offset = 0;
+    g.a_scale = a_scale_inv; g.b_scale = b_scale_inv;
+    const int took = sc_gemm8p_fp8(epi, g, (hipStream_t)stream);
+    SC_CHECK(took == 1, "sc_gemm_fp8: shape not supported (M=%d N=%d K=%d epi=%d)", M, N, K, epi);
+    return 0;
+}

@@ -710,7 +710,218 @@ int launch_tn(const GemmArgs& g, int nblocks, hipStream_t st) {
     return 1;
 }
 
+// =====================================================================================================================
+// FP8 (OCP e4m3) NT variant: the same tile, ring, phase schedule and epilogues on one-byte operands.  A half-tile row
+// is still 128 bytes, i.e. 128 k values instead of 64, so the staging stream, swizzle and waits are byte-for-byte the
+// bf16 kernel's; the caller passes K / 2, lda / 2, ldb / 2 ("bf16 elements") and the MFMA section issues ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 per fragment pair where the bf16 kernel issues two 16x16x32: half the MFMA count
+// for twice the k per tile = 2x the matrix rate.  Operand layout (probed with integer data, tools/micro/
+// mfma_fp8_layout.hip): lane (g = lane >> 4, r = lane & 15) supplies row r and the 32 consecutive k of bytes
+// [32 g, 32 g + 32) of the 128-byte row = the two 16-byte chunks 2g, 2g + 1; the block scales are E8M0 1.0 -- the real
+// scales are per-row floats applied to the accumulators before the epilogue:
+//     C[m][n] = a_scale[m] * b_scale[n] * sum_k A8[m][k] B8[n][k]   (+ bias, residual, GELU as in the bf16 kernel).
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+struct Frag8 {
+    union { i32x8 v; u32x4 h[2]; };
+};
+
+template <int D, int PH>
+SC_DEVICE void phase_f8(char* smem, const Stager& S, int t, const int (&a_off)[2], const int (&b_off)[2], Frag8 (&a)[4],
+                        Frag8 (&b0)[2], Frag8 (&b1)[2], f32x4 (&acc)[8][4]) {
+    if (PH == 1) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                b0[jj].h[kk] = *reinterpret_cast<const u32x4*>(smem + slot(D, 1) + b_off[kk] + jj * 2048);
+    }
+    if (PH == 2) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                b1[jj].h[kk] = *reinterpret_cast<const u32x4*>(smem + slot(D, 2) + b_off[kk] + jj * 2048);
+    }
+    if (PH == 1 || PH == 3) {
+        constexpr int sl = slot(D, PH == 1 ? 0 : 3);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+                a[ii].h[kk] = *reinterpret_cast<const u32x4*>(smem + sl + a_off[kk] + ii * 2048);
+    }
+    constexpr int q = (PH + 1) & 3;
+    constexpr int DS = PH <= 2 ? (D ^ 1) : D;
+    const int ts = t + (PH <= 2 ? 1 : 2);
+    if (ts < S.nt) {
+        dma16(S.src[q][0] + (size_t)ts * BK, smem + slot(DS, q) + S.wave * 1024);
+        dma16(S.src[q][1] + (size_t)ts * BK, smem + slot(DS, q) + (8 + S.wave) * 1024);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int mi = PH >= 3 ? 1 : 0;
+    constexpr int nj = (PH == 2 || PH == 3) ? 1 : 0;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            acc[mi * 4 + ii][nj * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                nj ? b1[jj].v : b0[jj].v, a[ii].v, acc[mi * 4 + ii][nj * 2 + jj], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int D>
+SC_DEVICE void ktile_f8(char* smem, const Stager& S, int t, const int (&a_off)[2], const int (&b_off)[2], Frag8 (&a)[4],
+                        Frag8 (&b0)[2], Frag8 (&b1)[2], f32x4 (&acc)[8][4]) {
+    phase_f8<D, 1>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+    phase_f8<D, 2>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+    phase_f8<D, 3>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+    phase_f8<D, 4>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+}
+
+// g.K / lda / ldb are in 2-byte units (see above); g.a_scale [M] and g.b_scale [N] are the dequantisation factors
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8p_f8_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+
+    int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = idx % g.ntn;
+    const int tm = idx / g.ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    Stager S;
+    S.nt = g.K / BK;
+    S.wave = wave;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = (p * 8 + wave) * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ga = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), g.M - 1);
+            const int gb = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), g.N - 1);
+            S.src[h ? 3 : 0][p] = g.A + (size_t)ga * g.lda + lc * 8;
+            S.src[h ? 2 : 1][p] = g.B + (size_t)gb * g.ldb + lc * 8;
+        }
+    }
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int coff = ((2 * lg + kk) ^ ((li >> 1) & 7)) << 4;       // bytes [32 lg + 16 kk, +16) of the row
+        a_off[kk] = (wr * 64 + li) * 128 + coff;
+        b_off[kk] = (wc * 32 + li) * 128 + coff;
+    }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int ts = s >> 2, q = s & 3;
+        if (ts < S.nt) {
+            dma16(S.src[q][0] + (size_t)ts * BK, smem + slot(ts & 1, q) + wave * 1024);
+            dma16(S.src[q][1] + (size_t)ts * BK, smem + slot(ts & 1, q) + (8 + wave) * 1024);
+        }
+    }
+    if (S.nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    Frag8 a[4], b0[2], b1[2];
+    for (int kt = 0; kt < S.nt; kt += 2) {
+        ktile_f8<0>(smem, S, kt, a_off, b_off, a, b0, b1, acc);
+        if (kt + 1 < S.nt) ktile_f8<1>(smem, S, kt + 1, a_off, b_off, a, b0, b1, acc);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // dequantise: lane owns C[m = .. + 16 i + li][n = .. + 16 j + 4 lg .. + 3]
+    {
+        const int mrow = m0 + wr * 128 + li, ncol = n0 + wc * 64 + lg * 4;
+        f32x4 sb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sb[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+            if (g.b_scale && ncol + j * 16 < g.N) sb[j] = *reinterpret_cast<const f32x4*>(g.b_scale + ncol + j * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float sa = g.a_scale ? g.a_scale[min(mrow + i * 16, g.M - 1)] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= sb[j] * sa;
+        }
+    }
+    if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) {
+        epilogue_bf16_lds<EPI>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
+    } else {
+        const int mw = wr * 128;
+        float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
+        EpiRegs<EPI> er;
+        sc_epi_load<EPI>(er, m0 + mw, n0 + wc * 64, lane, g, 64);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc_epi_put(ep, i, j, li, lg, acc[h * 4 + i][j]);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            sc_epilogue_store<EPI>(ep, er, m0 + mw + h * 64, n0 + wc * 64, lane, g, 0, (h + 1 < 2) ? m0 + mw + 64 : -1, 64);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int EPI>
+int launch_f8(const GemmArgs& g, int nblocks, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_f8_kernel<EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    gemm8p_f8_kernel<EPI><<<nblocks, 512, LDS_BYTES, st>>>(g);
+    SC_LAUNCH_CHECK();
+    return 1;
+}
+
 }  // namespace
+
+// fp8 NT GEMM: g.A / g.B point at e4m3 bytes, g.K / lda / ldb already halved ("2-byte units"); 1 = launched
+int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st) {
+    if (g.M < 1 || g.N < 8 || (g.K % BK) != 0) return 0;
+    g.ntm = (g.M + BM - 1) / BM;
+    g.ntn = (g.N + BN - 1) / BN;
+    g.splitk = 1;
+    g.k_per_split = g.K;
+    g.slab_stride = 0;
+    const int nblocks = g.ntm * g.ntn;
+    if (epi == SC_EPI_BF16) return launch_f8<SC_EPI_BF16>(g, nblocks, st);
+    if (epi == SC_EPI_BF16_BIAS) return launch_f8<SC_EPI_BF16_BIAS>(g, nblocks, st);
+    if (epi == SC_EPI_F32_BIAS_RES) return launch_f8<SC_EPI_F32_BIAS_RES>(g, nblocks, st);
+    if (epi == SC_EPI_GELU_PAIR) return launch_f8<SC_EPI_GELU_PAIR>(g, nblocks, st);
+    if (epi == SC_EPI_F32) return launch_f8<SC_EPI_F32>(g, nblocks, st);
+    return 0;
+}
 
 int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st) {
     if (g.M < 256 || g.N < 192 || (g.K % BK) != 0) return 0;

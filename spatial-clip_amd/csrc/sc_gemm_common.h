@@ -30,6 +30,8 @@ struct GemmArgs {
     int ntm, ntn;
     int tile_offset;      // first logical tile of this launch (tail launches of sc_gemm256)
     float* colsum;        // TN + EPI_F32 only: [splitk][M] partial column sums of the At operand (bias gradient), or null
+    const float* a_scale = nullptr;   // fp8 kernels only: per-row dequantisation factors of A [M] and B [N]
+    const float* b_scale = nullptr;
 };
 
 constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes and reads)
@@ -172,3 +174,5 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
 int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, float* c_final, hipStream_t st);
 // 256x256x64 phase-interleaved (ping-pong) kernel, NT only (sc_gemm8p.hip)
 int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
+// fp8 (e4m3) NT variant of the same kernel; g.K / lda / ldb in 2-byte units, g.a_scale / g.b_scale set
+int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st);

@@ -427,3 +427,45 @@ def augment_tiles(src_u8: torch.Tensor, params: torch.Tensor, out_size: int, mea
                                       ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), _stream()),
           "sc_augment_tiles")
     return out
+
+
+# ------------------------------------------------------------------------------------------ fp8 forward path
+def quantize_rows_fp8(src: torch.Tensor, dst: Optional[torch.Tensor] = None, scale_inv: Optional[torch.Tensor] = None,
+                      fixed_scale: float = 0.0):
+    """Row-wise e4m3 quantisation with a power-of-two scale per row: -> (fp8 bytes as uint8 [rows, cols], 1/scale [rows])."""
+    if not src.is_cuda or src.dtype not in (torch.float32, torch.bfloat16) or src.dim() != 2 or src.stride(1) != 1:
+        raise TypeError("quantize_rows_fp8: src must be a device fp32 / bf16 matrix with unit inner stride")
+    rows, cols = src.shape
+    if dst is None:
+        dst = torch.empty((rows, cols), dtype=torch.uint8, device=src.device)
+    if scale_inv is None:
+        scale_inv = torch.empty(rows, dtype=torch.float32, device=src.device)
+    check(_lib.lib().sc_quantize_rows_fp8(src.data_ptr(), int(src.dtype == torch.float32), src.stride(0), rows, cols,
+                                          dst.data_ptr(), dst.stride(0), scale_inv.data_ptr(), float(fixed_scale),
+                                          _stream()), "sc_quantize_rows_fp8")
+    return dst, scale_inv
+
+
+def gemm_fp8(epi: int, a8: torch.Tensor, a_scale_inv: torch.Tensor, b8: torch.Tensor, b_scale_inv: torch.Tensor,
+             out: torch.Tensor, *, M: int, N: int, K: int, out2: Optional[torch.Tensor] = None,
+             bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C[M,N] = dequant(A8[M,K] . B8[N,K]^T) with the bf16 GEMM's forward epilogues (see sc_gemm_fp8)."""
+    for t_, n in ((a8, "a8"), (b8, "b8")):
+        if not t_.is_cuda or t_.dtype != torch.uint8 or t_.stride(-1) != 1:
+            raise TypeError(f"gemm_fp8: {n} must be a device uint8 (e4m3 bytes) matrix")
+    _req(a_scale_inv, torch.float32, "a_scale_inv"); _req(b_scale_inv, torch.float32, "b_scale_inv")
+    want = torch.float32 if epi in (EPI_F32, EPI_F32_BIAS_RES) else torch.bfloat16
+    _req(out, want, "out")
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    rc = _lib.lib().sc_gemm_fp8(epi, a8.data_ptr(), a8.stride(0), a_scale_inv.data_ptr(), b8.data_ptr(), b8.stride(0),
+                                b_scale_inv.data_ptr(), M, N, K, out.data_ptr(), out.stride(0), _ptr(out2),
+                                out2.stride(0) if out2 is not None else 0, _ptr(bias), _ptr(res),
+                                res.stride(0) if res is not None else 0, _stream())
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append(("gemm_nt_fp8", 2.0 * M * N * K, ev))
+    check(rc, "sc_gemm_fp8")
+    return out
