@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-loss-delta", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: e4m3 forward GEMMs of the transformer blocks (BASELINE configs[4]); backward stays bf16")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -223,7 +225,7 @@ def main():
         print(f"bench.py: live process group has {dist.get_world_size()} ranks, wanted {args.gpus}", file=sys.stderr)
         sys.exit(2)
 
-    n = net.SpatialClipNet(args.model, None, n_genes=args.n_genes, seed=0)
+    n = net.SpatialClipNet(args.model, None, n_genes=args.n_genes, seed=0, precision=args.dtype)
     cfg = n.cfg
     if args.loss == "clip":
         loss_fn = losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True)
@@ -330,6 +332,8 @@ def main():
     if events:
         agg = aggregate(events)
         dom = "gemm_nt"
+        if "gemm_nt_fp8" in agg:                 # fp8 run: forward launches are the e4m3 kernel; report them beside the bf16 ones
+            f8, s8, c8 = agg["gemm_nt_fp8"]
         fl, sec, cnt = agg[dom]
         ach = fl / sec / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm8p_kernel / gemm8pp_kernel (NT: forward + dgrad GEMMs)", "achieved": round(ach, 1),
@@ -346,6 +350,11 @@ def main():
             roofline["with_side_stream"] = {"achieved": round(fo / so / 1e12, 1), "avg_launch_us": round(so / co * 1e6, 1),
                                             "instrumented_ms_per_step": round(dt_ov / args.steps * 1e3, 3),
                                             "note": "same launches while the weight-gradient GEMMs share the chip (the shipped schedule)"}
+        if "gemm_nt_fp8" in agg:
+            roofline["forward_fp8"] = {"achieved": round(f8 / s8 / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
+                                       "frac": round(f8 / s8 / 1e12 / 5000.0, 4), "launches_per_step": c8 // args.steps,
+                                       "share_of_step_time": round(s8 / dt_inst, 3),
+                                       "note": "v_mfma_scale_f32_16x16x128_f8f6f4 forward GEMMs (e4m3, dense fp8 peak ~5 PFLOP/s)"}
         if "gemm_tn" in agg:
             fl2, sec2, cnt2 = agg["gemm_tn"]
             roofline["wgrad_tn"] = {"achieved": round(fl2 / sec2 / 1e12, 1), "share_of_step_time": round(sec2 / dt_inst, 3),
@@ -373,7 +382,7 @@ def main():
         out = {"metric": "tile-gene pairs/sec (train step)", "value": round(value, 2), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"{args.model} image tower + " + (
                           f"gene-MLP({args.n_genes}->{cfg.gene.hidden}->{cfg.embed_dim}), " if cfg.gene.kind == "mlp" else
                           f"{cfg.gene.layers}-layer gene transformer({args.n_genes} genes -> {cfg.gene.tokens} tokens x "

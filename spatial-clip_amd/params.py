@@ -50,6 +50,8 @@ class LinearCopy:
     k_pad: int = 0
     wf: Optional[torch.Tensor] = None
     wb: Optional[torch.Tensor] = None
+    w8: Optional[torch.Tensor] = None       # fp8 path: e4m3 bytes [N_out, K_in] + per-output-channel dequantisation factors
+    w8s: Optional[torch.Tensor] = None
 
 
 def _block_specs(prefix: str, d: int, mlp: int) -> List[ParamSpec]:
@@ -126,9 +128,10 @@ def build_specs(cfg: ModelCfg) -> List[ParamSpec]:
 
 
 class ParamStore:
-    def __init__(self, cfg: ModelCfg, device: torch.device, seed: int = 0):
+    def __init__(self, cfg: ModelCfg, device: torch.device, seed: int = 0, fp8: bool = False):
         self.cfg = cfg
         self.device = device
+        self.fp8 = fp8          # forward GEMMs of the transformer blocks in e4m3 (BASELINE configs[4]); see csrc/sc_fp8.hip
         self.specs = build_specs(cfg)
         self.by_name = {s.name: s for s in self.specs}
         last = self.specs[-1]
@@ -231,6 +234,14 @@ class ParamStore:
             self._add_copy(prefix + "attn.out_proj.weight", dd, dd)
             self._add_copy(prefix + "mlp.c_fc.weight", mlp, dd)
             self._add_copy(prefix + "mlp.c_proj.weight", dd, mlp)
+            if self.fp8:
+                if dd % 128 or mlp % 128:
+                    raise ValueError(f"fp8 path needs block widths that are multiples of 128 (got {dd} / {mlp})")
+                for leaf, n_out, k_in in (("attn.in_proj_weight", 3 * dd, dd), ("attn.out_proj.weight", dd, dd),
+                                          ("mlp.c_fc.weight", mlp, dd), ("mlp.c_proj.weight", dd, mlp)):
+                    c = self.copies[prefix + leaf]
+                    c.w8 = torch.zeros((n_out, k_in), dtype=torch.uint8, device=self.device)
+                    c.w8s = torch.ones(n_out, dtype=torch.float32, device=self.device)
 
         for i in range(v.layers):
             block(f"visual.transformer.resblocks.{i}.", d, int(d * v.mlp_ratio))
@@ -279,6 +290,10 @@ class ParamStore:
             self._build_transpose_plan()
         if self._tp_n:
             ops.cast_transpose_batched(self.master, self._tp_desc, self._tp_prefix, self._tp_n, self._tp_tiles)
+        if self.fp8:                                      # per-output-channel e4m3 copies straight from the fp32 masters
+            for c in self.copies.values():
+                if c.w8 is not None:
+                    ops.quantize_rows_fp8(self.p(c.name).view(c.n_out, c.k_in), c.w8, c.w8s)
         for c in self.copies.values():
             if not c.stored_kn and not c.wf_is_view:      # K-padded forward operand (gene.fc1, conv1 at patch 14)
                 ops.cast_pad_bf16(self.p(c.name).view(c.n_out, c.k_in), c.wf, c.n_out, c.k_in, c.k_pad,

@@ -63,6 +63,18 @@ class TransformerStack:
         self.d, self.H, self.layers, self.mlp, self.causal = width, heads, layers, mlp, causal
         self.dh = width // heads
         self.bufs = _Bufs(store.device)
+        self.fp8 = bool(getattr(store, "fp8", False))
+
+    def _linear_fwd(self, epi: int, x: torch.Tensor, name: str, out: torch.Tensor, *, M: int, N: int, K: int, **kw):
+        """One forward Linear of a full-width block: bf16 MFMA GEMM, or (fp8 path) per-row e4m3 quantisation of the
+        activation rows followed by the fp8 MFMA GEMM against the per-channel-quantised weight."""
+        cp = self.s.copies[name]
+        if not self.fp8:
+            return ops.gemm(ops.NT, epi, x, cp.wf, out, M=M, N=N, K=K, **kw)
+        q8 = self.bufs.get(f"q8.{K}", (M, K), torch.uint8)
+        qs = self.bufs.get("q8.scale", (M,), F32)
+        ops.quantize_rows_fp8(x, q8, qs)
+        return ops.gemm_fp8(epi, q8, qs, cp.w8, cp.w8s, out, M=M, N=N, K=K, **kw)
 
     def _n(self, i: int, leaf: str) -> str:
         return f"{self.prefix}{i}.{leaf}"
@@ -88,27 +100,27 @@ class TransformerStack:
             r1 = bf.get(f"r1.{i}", (M,), F32)
             ops.layernorm_fwd(x, s.p(self._n(i, "ln_1.weight")), s.p(self._n(i, "ln_1.bias")), a1, m1, r1, M, d)
             qkv = bf.get(f"qkv.{i}", (M, 3 * d), BF16)
-            ops.gemm(ops.NT, ops.EPI_BF16_BIAS, a1, s.copies[self._n(i, "attn.in_proj_weight")].wf, qkv,
-                     M=M, N=3 * d, K=d, bias=s.p(self._n(i, "attn.in_proj_bias")))
+            self._linear_fwd(ops.EPI_BF16_BIAS, a1, self._n(i, "attn.in_proj_weight"), qkv,
+                             M=M, N=3 * d, K=d, bias=s.p(self._n(i, "attn.in_proj_bias")))
             o = bf.get(f"o.{i}", (M, d), BF16)
             lse = bf.get(f"lse.{i}", (B, H, L), F32)
             if self.cls_only_last and i == self.layers - 1:
                 return self._forward_last_cls(i, x, qkv, o, lse)
             ops.attn_fwd(qkv, B, L, H, dh, self.causal, out=o, lse=lse)
             xmid = bf.get(f"xmid.{i}", (M, d), F32)
-            ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, o, s.copies[self._n(i, "attn.out_proj.weight")].wf, xmid,
-                     M=M, N=d, K=d, bias=s.p(self._n(i, "attn.out_proj.bias")), res=x)
+            self._linear_fwd(ops.EPI_F32_BIAS_RES, o, self._n(i, "attn.out_proj.weight"), xmid,
+                             M=M, N=d, K=d, bias=s.p(self._n(i, "attn.out_proj.bias")), res=x)
             a2 = bf.get(f"a2.{i}", (M, d), BF16)
             m2 = bf.get(f"m2.{i}", (M,), F32)
             r2 = bf.get(f"r2.{i}", (M,), F32)
             ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2, m2, r2, M, d)
             u = bf.get(f"u.{i}", (M, mlp), BF16)
             h = bf.get(f"h.{i}", (M, mlp), BF16)
-            ops.gemm(ops.NT, ops.EPI_GELU_PAIR, a2, s.copies[self._n(i, "mlp.c_fc.weight")].wf, u,
-                     M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)
+            self._linear_fwd(ops.EPI_GELU_PAIR, a2, self._n(i, "mlp.c_fc.weight"), u,
+                             M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)
             xo = bf.get(f"xout.{i}", (M, d), F32)
-            ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, h, s.copies[self._n(i, "mlp.c_proj.weight")].wf, xo,
-                     M=M, N=d, K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
+            self._linear_fwd(ops.EPI_F32_BIAS_RES, h, self._n(i, "mlp.c_proj.weight"), xo,
+                             M=M, N=d, K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
             x = xo
         return x
 

@@ -88,7 +88,9 @@ def test_gemm_fp8_accuracy_on_activation_like_data():
     out = torch.empty((M, N), device="cuda")
     ops.gemm_fp8(ops.EPI_F32, a8, sa, w8, sw, out, M=M, N=N, K=K)
     exact = deq(a8, sa).double() @ deq(w8, sw).double().t()
-    assert float((out.double() - exact).abs().max() / exact.abs().max()) < 1e-5
+    # the 128-deep MFMA aligns its products to the largest one before adding them (a ~2^-12 floor relative to the biggest
+    # term of the instruction, visible here because of the x30 outlier channel), then accumulates in fp32
+    assert float((out.double() - exact).abs().max() / exact.abs().max()) < 1e-3
     full = a.bfloat16().float().cuda().double() @ w.cuda().double().t()
     rel = float((out.double() - full).norm() / full.norm())
     print(f"[fp8] relative Frobenius error vs the unquantised product: {rel:.4f}")
@@ -112,3 +114,66 @@ def test_gemm_fp8_accuracy_on_activation_like_data():
     t8 = t(lambda: ops.gemm_fp8(ops.EPI_BF16, a8, sa, w8, sw, o8, M=M, N=N, K=K))
     fl = 2.0 * M * N * K
     print(f"[fp8] {M}x{N}x{K}: bf16 {tb * 1e3:.0f} us ({fl / tb / 1e9:.0f} TFLOP/s), fp8 {t8 * 1e3:.0f} us ({fl / t8 / 1e9:.0f} TFLOP/s)")
+
+
+def test_fp8_model_step_against_fp32_oracle_stated_tolerance():
+    """The stated bound of the fp8 path: with e4m3 forward GEMMs in both towers' blocks the loss stays
+    within 1e-2 and the unit-norm features within 4e-2 (max abs) of the fp32 oracle on identical weights and batch
+    (measured: 1.6e-3 / 8e-3 here, 3.0e-3 / 2.8e-2 at ViT-L/14 B=256); gradients (bf16 backward through fp8-perturbed
+    activations) within 25 % of each tensor's max-abs (worst tensor measured 20 %); optimiser steps still reduce the loss."""
+    import functools
+    from oracle import spatial_clip_oracle as O
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data, losses, model_configs as mc, module, net, optim
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 128, 3, 64), text=None,
+                      gene=mc.GeneCfg(512, 0, "transformer", 64, 128, 2, 64))
+    ocfg = O.ModelCfg(embed_dim=64, vision=O.VisionCfg(32, 8, 128, 3, 64), text=None,
+                      gene=O.GeneCfg(512, 0, "transformer", 64, 128, 2, 64))
+    n8 = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=9, precision="fp8")
+    assert n8.store.fp8 and n8.store.copies["visual.transformer.resblocks.0.mlp.c_fc.weight"].w8 is not None
+    params = {k: v.cpu() for k, v in n8.state_dict().items()}
+    B = 32
+    batch = data.synthetic_batch(B, 32, 512, K=4, step=0)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f = O.net_forward(batch["images"], batch["texts"], p, ocfg)
+    lo = O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"])
+    lo.backward()
+    loss_fn = losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True)
+    m = module.SpatialClipLitModule(
+        n8, loss_fn, functools.partial(optim.FusedAdamW, lr=2e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+    db = {k: v.cuda() for k, v in batch.items()}
+    out = m.model_step(db)
+    dl = abs(float(out["loss"].detach()) - float(lo.detach()))
+    dfi = float((out["image_features"].cpu() - f["image_features"].detach()).abs().max())
+    dft = float((out["text_features"].cpu() - f["text_features"].detach()).abs().max())
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k in params:
+        if p[k].grad is None or float(p[k].grad.abs().max()) == 0:
+            continue
+        worst = max(worst, float((n8.store.g(k).cpu() - p[k].grad).abs().max() / p[k].grad.abs().max()))
+    print(f"[fp8 model] |d loss| = {dl:.2e}, max |d feature| image {dfi:.2e} text {dft:.2e}, worst grad rel err {worst:.3f}")
+    assert dl < 1e-2 and dfi < 4e-2 and dft < 4e-2 and worst < 0.25
+
+    class T:
+        max_steps, max_epochs, estimated_stepping_batches = 20, None, 20
+    m.trainer = T()
+    oc = m.configure_optimizers()
+    opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+    ls = []
+    for step in range(8):
+        loss = m.training_step(db, step)
+        loss.backward()
+        opt.step(grad_scale=1.0, max_norm=1.0)
+        sched.step()
+        ls.append(float(loss.detach()))
+    assert all(l == l for l in ls) and ls[-1] < ls[1] - 0.05, ls
+    w8 = n8.store.copies["visual.transformer.resblocks.0.mlp.c_fc.weight"]
+    back = w8.w8.view(torch.float8_e4m3fn).float() * w8.w8s[:, None]
+    ref = n8.store.p("visual.transformer.resblocks.0.mlp.c_fc.weight")
+    assert float((back - ref).abs().max() / ref.abs().max()) < 2.0 ** -4      # fp8 copies follow the optimiser
+    with pytest.raises(ValueError, match="multiples of 128"):
+        net.SpatialClipNet("custom", None, model_cfg=mc.ModelCfg(32, mc.VisionCfg(32, 8, 64, 2, 32), None, mc.GeneCfg(200, 64)),
+                           precision="fp8")
