@@ -95,6 +95,7 @@ def cpu_baseline_leg(model_name: str, n_genes: int, B: int, steps: int = 3, loss
     ocfg = _oracle_cfg(cfg)
     cores = host_cpu_share()
     torch.set_num_threads(cores)
+    O.USE_ATEN_KERNELS = True       # timed form: same maths through the ATen kernels the reference runs (oracle header)
     tr = O.OracleTrainer(ocfg, O.init_params(ocfg, seed=0), loss=loss, lr=1e-3, warmup=2000)
     rates = data.make_gene_rates(n_genes)
     times = []
@@ -104,6 +105,7 @@ def cpu_baseline_leg(model_name: str, n_genes: int, B: int, steps: int = 3, loss
         tr.training_step(batch)
         times.append(time.time() - t0)
     timed = sorted(times[1:])
+    O.USE_ATEN_KERNELS = False
     return {"workload": f"{model_name}, n_genes={n_genes}, B={B}", "pairs_per_s_best": round(B / timed[0], 3),
             "pairs_per_s_median": round(B / timed[len(timed) // 2], 3), "step_s": [round(t, 3) for t in times]}
 

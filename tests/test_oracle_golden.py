@@ -184,3 +184,29 @@ def test_zero_shot_metric_oracle_matches_reference_class(golden_dir):
         n += rows.numel()
         assert abs(tot - j["sum_after"][i]) < 1e-6
     assert n == j["total_count"] and abs(tot / n - j["compute"]) < 1e-7
+
+
+def test_aten_kernel_mode_matches_plain_mode():
+    """The timed form of the oracle (bench.py cpu_baseline: stock ATen kernels, foreach optimiser) computes the same
+    training step as the spelled-out restatement: losses, gradient norm and post-step weights agree to fp32 rounding."""
+    cfg = O.ModelCfg(32, O.VisionCfg(32, 8, 64, 2, 32), O.TextCfg(12, 50, 64, 2, 2), None)
+    params = O.init_params(cfg, 3)
+    g = torch.Generator().manual_seed(0)
+    texts = torch.randint(1, 48, (6, 12), generator=g)
+    texts[:, -1] = 49
+    batch = {"images": torch.randn(6, 3, 32, 32, generator=g), "texts": texts}
+    outs = []
+    for mode in (False, True):
+        O.USE_ATEN_KERNELS = mode
+        try:
+            tr = O.OracleTrainer(cfg, params, loss="clip", lr=1e-2, warmup=0, total_steps=100)
+            r = [tr.training_step(batch) for _ in range(3)]
+        finally:
+            O.USE_ATEN_KERNELS = False
+        outs.append((r, tr.p))
+    (ra, pa), (rb, pb) = outs
+    for a, b in zip(ra, rb):
+        assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5          # lr 1e-2: three steps amplify fp32 rounding
+        assert abs(float(a["grad_norm"]) - float(b["grad_norm"])) < 1e-5 * max(1.0, float(a["grad_norm"]))
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) < 2e-5, k
