@@ -522,7 +522,12 @@ extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, c
     hipStream_t st = (hipStream_t)stream;
     const int Lp = (L + 31) & ~31;
     const float scale = 1.0f / sqrtf((float)dh);
-    // fused single-kernel form when Q, K, V and dO of a head fit LDS together (L <= 304 at dh = 64)
+    static const bool single_on = !(getenv("SC_ATTN_BWD1") && getenv("SC_ATTN_BWD1")[0] == '0');
+    if (single_on && sc_attn_bwd_single_pass(qkv, out, dout, lse, delta, dqkv, B, L, Lq, H, dh, causal, st)) {
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
+    // fused two-pass kernel when Q, K, V and dO of a head fit LDS together (L <= 304 at dh = 64)
     static const bool fused_on = !(getenv("SC_ATTN_FUSED") && getenv("SC_ATTN_FUSED")[0] == '0');
     const size_t lds_fused = (size_t)4 * Lp * dh * 2 + (size_t)2 * Lp * 4;
     if (fused_on && lds_fused <= 160 * 1024) {

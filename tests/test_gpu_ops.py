@@ -80,6 +80,34 @@ def test_attention_fwd_persistent_walks_many_heads(B, L, H, causal, q_rows):
         assert bool((o[:, nq:] == 7.0).all()) and bool((lse.cpu()[:, :, nq:] == 7.0).all())
 
 
+@pytest.mark.parametrize("B,L,H,causal", [(26, 197, 12, False), (40, 77, 8, True), (300, 33, 1, False), (9, 224, 30, True),
+                                          (3, 100, 2, False)])
+def test_attention_bwd_single_pass_walks_many_heads(B, L, H, causal):
+    """Single-pass backward (dQ summed over the key waves in an fp32 LDS accumulator, fixed order): more heads than CUs
+    so that a persistent workgroup walks several heads (accumulator re-zeroed by the flush); gradients against autograd
+    and bit-identical across two launches (no float atomics)."""
+    ops = _ops()
+    dh = 64
+    d = H * dh
+    g = torch.Generator().manual_seed(B * 7 + L)
+    qkv = bf(torch.randn(B * L, 3 * d, generator=g))
+    dout = bf(torch.randn(B * L, d, generator=g))
+    x = qkv.float().requires_grad_(True)
+    o_ref, _ = ref_attn(x, B, L, H, dh, causal)
+    o_ref.backward(dout.float())
+    qd, gd = qkv.cuda(), dout.cuda()
+    out, lse = ops.attn_fwd(qd, B, L, H, dh, causal)
+    dq1 = torch.full((B * L, 3 * d), 7.0, dtype=torch.bfloat16, device="cuda")
+    delta1 = torch.empty(B, H, L, device="cuda")
+    ops.attn_bwd(qd, out, gd, lse, B, L, H, dh, causal, dqkv=dq1, delta=delta1)
+    dq2 = torch.full_like(dq1, 3.0)
+    ops.attn_bwd(qd, out, gd, lse, B, L, H, dh, causal, dqkv=dq2)
+    assert torch.equal(dq1, dq2)
+    torch.testing.assert_close(dq1.float().cpu(), x.grad, atol=4e-2, rtol=4e-2)
+    want_delta = (dout.float() * out.float().cpu()).view(B, L, H, dh).sum(-1).permute(0, 2, 1)
+    torch.testing.assert_close(delta1.cpu(), want_delta, atol=2e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("rows,d", [(50, 768), (197 * 2, 192), (33, 64), (7, 1024)])
 def test_layernorm_fwd_bwd(rows, d):
     ops = _ops()
