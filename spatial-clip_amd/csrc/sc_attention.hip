@@ -522,13 +522,20 @@ extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, c
     hipStream_t st = (hipStream_t)stream;
     const int Lp = (L + 31) & ~31;
     const float scale = 1.0f / sqrtf((float)dh);
-    static const bool single_on = !(getenv("SC_ATTN_BWD1") && getenv("SC_ATTN_BWD1")[0] == '0');
+    // 1) single-pass (non-causal, L <= 224): 232-256 us per ViT-B/16 layer; 2) persistent two-pass with loader waves
+    // (also causal): 254 us; 3) one workgroup per head: 268-296 us.  The switches are read per call (tests select a path).
+    const bool single_on = !(getenv("SC_ATTN_BWD1") && getenv("SC_ATTN_BWD1")[0] == '0');
     if (single_on && sc_attn_bwd_single_pass(qkv, out, dout, lse, delta, dqkv, B, L, Lq, H, dh, causal, st)) {
         SC_LAUNCH_CHECK();
         return 0;
     }
+    const bool persist_on = !(getenv("SC_ATTN_BWD2") && getenv("SC_ATTN_BWD2")[0] == '0');
+    if (persist_on && sc_attn_bwd_persistent(qkv, out, dout, lse, delta, dqkv, B, L, Lq, H, dh, causal, st)) {
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     // fused two-pass kernel when Q, K, V and dO of a head fit LDS together (L <= 304 at dh = 64)
-    static const bool fused_on = !(getenv("SC_ATTN_FUSED") && getenv("SC_ATTN_FUSED")[0] == '0');
+    const bool fused_on = !(getenv("SC_ATTN_FUSED") && getenv("SC_ATTN_FUSED")[0] == '0');
     const size_t lds_fused = (size_t)4 * Lp * dh * 2 + (size_t)2 * Lp * 4;
     if (fused_on && lds_fused <= 160 * 1024) {
         const size_t lds = lds_fused;

@@ -28,33 +28,9 @@
 
 namespace {
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
-}
-SC_DEVICE void wg_barrier() {          // the bare builtin is IntrNoMem: pin the surrounding LDS accesses
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 constexpr int BDH = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int NSTORE = 2 * 2 * 2 + 4;        // per compute wave and head: dK / dV stores (2 tensors x 2 key tiles x 2 halves) + 4 dQ flush stores
-
-SC_DEVICE unsigned lds_peek(unsigned addr) {         // one LDS word, read now (asm: no compiler-side caching or reordering)
-    unsigned v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return __builtin_amdgcn_readfirstlane(v);
-}
-SC_DEVICE void lds_bump(unsigned addr) {             // +1, ordered behind this wave's earlier LDS operations
-    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
-}
-SC_DEVICE void lds_wait_ge(unsigned addr, unsigned want) {
-    while (lds_peek(addr) < want) __builtin_amdgcn_s_sleep(1);
-}
 
 // Overlap (the kernel is memory-heavy: 618 MB per ViT-B/16 layer = ~100 us at the HBM rate, against ~130 us of compute):
 //   * wave NB is a HELPER (s_setprio 3): while the compute waves sweep head i it streams K of head i+1 into the K image

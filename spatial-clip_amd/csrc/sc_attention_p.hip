@@ -29,13 +29,6 @@
 
 namespace {
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
-}
-
 constexpr int PDH = 64;                 // head dim of this kernel
 constexpr int QSLOT = 16 * PDH * 2;     // one 16-query tile: 2 KiB
 #ifndef SC_ATTN_NLOAD
@@ -46,12 +39,6 @@ constexpr int NLOAD = SC_ATTN_NLOAD;    // loader waves per workgroup
 #define SC_ATTN_QSYNC 1
 #endif
 
-// s_barrier is IntrNoMem to the compiler: ordinary LDS loads may be moved across the bare builtin.  Pin them.
-SC_DEVICE void wg_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 SC_DEVICE float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 // Wave roles.  Compute waves 0 .. nqt-1 own one 16-query tile each; the last NLOAD waves only move data: they issue

@@ -14,6 +14,10 @@ int sc_attn_fwd_persistent(const void* qkv, void* out, float* lse, int B, int L,
 int sc_attn_bwd_single_pass(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                             int B, int L, int Lq, int H, int dh, int causal, hipStream_t st);
 
+// sc_attention_bwd2.hip: persistent two-pass backward with loader waves; 1 = launched, 0 = shape out of range
+int sc_attn_bwd_persistent(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                           int B, int L, int Lq, int H, int dh, int causal, hipStream_t st);
+
 namespace {
 
 constexpr int MAXL = 320;
@@ -148,5 +152,30 @@ SC_DEVICE f32x4 exp2_affine(f32x4 x, float c, float b) {
     return (f32x4){fast_exp2(a[0]), fast_exp2(a[1]), fast_exp2(a[2]), fast_exp2(a[3])};
 }
 
+// ---- pieces of the persistent kernels (LDS-DMA loader / helper waves, LDS arrival counters)
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// 64 lanes x 16 bytes, global -> LDS without a trip through registers; destination = wave base + 16 * lane
+SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+// s_barrier is IntrNoMem to the compiler: ordinary LDS loads may be moved across the bare builtin.  Pin them.
+SC_DEVICE void wg_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+SC_DEVICE unsigned lds_peek(unsigned addr) {         // one LDS word, read now (asm: no compiler-side caching or reordering)
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+SC_DEVICE void lds_bump(unsigned addr) {             // +1, ordered behind this wave's earlier LDS operations
+    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+}
+SC_DEVICE void lds_wait_ge(unsigned addr, unsigned want) {
+    while (lds_peek(addr) < want) __builtin_amdgcn_s_sleep(1);
+}
 
 }  // namespace

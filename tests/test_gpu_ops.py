@@ -80,13 +80,18 @@ def test_attention_fwd_persistent_walks_many_heads(B, L, H, causal, q_rows):
         assert bool((o[:, nq:] == 7.0).all()) and bool((lse.cpu()[:, :, nq:] == 7.0).all())
 
 
+@pytest.mark.parametrize("path", ["persistent", "single_pass", "per_head"])
 @pytest.mark.parametrize("B,L,H,causal", [(26, 197, 12, False), (40, 77, 8, True), (300, 33, 1, False), (9, 224, 30, True),
                                           (3, 100, 2, False)])
-def test_attention_bwd_single_pass_walks_many_heads(B, L, H, causal):
-    """Single-pass backward (dQ summed over the key waves in an fp32 LDS accumulator, fixed order): more heads than CUs
-    so that a persistent workgroup walks several heads (accumulator re-zeroed by the flush); gradients against autograd
-    and bit-identical across two launches (no float atomics)."""
+def test_attention_bwd_paths_walk_many_heads(B, L, H, causal, path, monkeypatch):
+    """The three backward kernels behind sc_attn_bwd (selected per call by SC_ATTN_BWD1 / SC_ATTN_BWD2):
+    single-pass (default; dQ summed over the key waves in an fp32 LDS accumulator, fixed order; non-causal only,
+    otherwise it declines and the next kernel runs), persistent two-pass with loader waves, one workgroup per head.
+    More heads than CUs so that a persistent workgroup walks several heads; gradients against autograd and
+    bit-identical across two launches (no float atomics)."""
     ops = _ops()
+    monkeypatch.setenv("SC_ATTN_BWD1", "1" if path == "single_pass" else "0")      # tried first
+    monkeypatch.setenv("SC_ATTN_BWD2", "1" if path == "persistent" else "0")       # tried second
     dh = 64
     d = H * dh
     g = torch.Generator().manual_seed(B * 7 + L)

@@ -28,10 +28,13 @@ def timeit(fn, name, bytes_):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
-    print(f"{name:10s} {us:8.1f} us   {bytes_ / us / 1e6:6.2f} TB/s algorithmic", flush=True)
+    print(f"{name:16s} {us:8.1f} us   {bytes_ / us / 1e6:6.2f} TB/s algorithmic", flush=True)
 
 
 qb = qkv.numel() * 2
 ob = out.numel() * 2
 timeit(lambda: ops.attn_fwd(qkv, B, L, H, dh, False, out=out, lse=lse), "fwd", qb + ob)
-timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, dh, False, dqkv=dqkv, delta=delta), "bwd", 2 * qb + 3 * ob + qb)
+for name, b2, b1 in (("bwd persistent", "1", "0"), ("bwd single-pass", "0", "1"), ("bwd per-head", "0", "0")):
+    os.environ["SC_ATTN_BWD2"], os.environ["SC_ATTN_BWD1"] = b2, b1
+    timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, dh, False, dqkv=dqkv, delta=delta), name, 2 * qb + 3 * ob + qb)
+os.environ.pop("SC_ATTN_BWD2"); os.environ.pop("SC_ATTN_BWD1")
