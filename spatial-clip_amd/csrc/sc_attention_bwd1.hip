@@ -48,6 +48,7 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const bf16* __restrict__
                                                         const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                         float* __restrict__ delta, bf16* __restrict__ dqkv, int L, int H,
                                                         int nheads, float scale, unsigned dq_bytes) {
+    static_assert(!CAUSAL, "the first-contributor overwrite of the dQ accumulator assumes every (wave, block) step is live");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int DH = BDH, KS = DH / 32, DT = DH / 16;
     constexpr int Lp = NB * 32;
@@ -148,8 +149,7 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const bf16* __restrict__
     const int kb = wave * 32;                           // this wave's keys
     char* scratch = scratch0 + wave * 2048;
     const __amdgpu_buffer_rsrc_t dq_rsrc = sc_make_rsrc(dqkv, dq_bytes);
-    // zero the dQ accumulator and the counters once; every head's flush leaves the accumulator zeroed again
-    for (int i = t; i < Lp * DH / 4; i += NW * 64) reinterpret_cast<f32x4*>(dQacc)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the counters start at zero; the dQ accumulator needs no fill (the first contributor of a block overwrites)
     if (t < 1 + NB) asm volatile("ds_write_b32 %0, %1" ::"v"(ctr0 + 4 * t), "v"(0u) : "memory");
 
     auto load_vf = [&](int head, bf16x8 (&vf)[2][KS]) {
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const bf16* __restrict__
                     for (int dt = 0; dt < DT; ++dt) {
                         const f32x4 dq = sc_mfma16(ktr[dt], dst[a], (f32x4){0.f, 0.f, 0.f, 0.f});
                         f32x4* cell = reinterpret_cast<f32x4*>(arow + (((dt * 4 + lg) ^ (q & 15)) << 2));
-                        *cell = *cell + dq;
+                        if (step == 0) *cell = dq;                  // first contribution of the head: no read, no zero-fill
+                        else *cell = *cell + dq;
                     }
                 }
             } else {
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const bf16* __restrict__
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        // flush dQ (bf16, x scale) and leave the accumulator zeroed for the next head: 4 trips of 16-byte stores per lane
+        // flush dQ (bf16, x scale): 4 trips of 16-byte stores per lane
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * (NW * 64) + t;
@@ -332,8 +333,6 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const bf16* __restrict__
             f32x4* c0 = reinterpret_cast<f32x4*>(dQacc + row * DH + ((c2x ^ (row & 15)) << 2));
             f32x4* c1 = reinterpret_cast<f32x4*>(dQacc + row * DH + (((c2x + 1) ^ (row & 15)) << 2));
             const f32x4 v0 = *c0, v1 = *c1;
-            *c0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o[e] = (bf16)(v0[e] * scale); o[4 + e] = (bf16)(v1[e] * scale); }
