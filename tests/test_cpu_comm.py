@@ -7,6 +7,7 @@ run (tests/golden/loss_w2.npz)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -125,9 +126,11 @@ def _fg_worker(rank, world, port, ret):
     comm.shutdown()
 
 
-def test_feature_gather_matches_synchronous_gather_two_ranks():
+@pytest.mark.parametrize("world", [2, 4])
+def test_feature_gather_matches_synchronous_gather(world):
+    """Overlapped gather == synchronous packed gather on 2 and on 4 gloo ranks (rank-major row order, 64-bit ids)."""
     mp.set_start_method("spawn", force=True)
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_fg_worker, args=(2, 29621, ret), nprocs=2, join=True)
-        assert dict(ret) == {0: 3, 1: 3}
+        mp.spawn(_fg_worker, args=(world, 29621 + world, ret), nprocs=world, join=True)
+        assert dict(ret) == {r: 3 for r in range(world)}
