@@ -69,8 +69,9 @@ int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, cons
  * out[B*L, H*dh] bf16, lse[B,H,L] fp32 (log-sum-exp of the scaled scores, kept for backward).
  * sc_attn_bwd writes dqkv[B*L, 3*H*dh] (bf16) and uses delta[B,H,L] as scratch.  L <= 320, dh in {32, 64}.
  * q_rows > 0 restricts the work to the first q_rows query positions of every sequence (the last ViT block only
- * feeds the CLS token downstream): outputs / dq of the other rows are not written, dk / dv receive only those
- * queries' contributions; dout / out of the unused rows may hold any FINITE values (they meet exact zeros only). */
+ * feeds the CLS token downstream): outputs of the other rows are not written, dk / dv receive only those queries'
+ * contributions; dout / out of the unused rows may hold any FINITE values (they meet exact zeros only).  dq of the
+ * other rows: q_rows == 1 writes exact zeros (the caller needs no memset of dqkv); 1 < q_rows < L leaves them untouched. */
 int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dh, int causal, int q_rows,
                 void* stream);
 int sc_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,

@@ -522,6 +522,10 @@ extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, c
     hipStream_t st = (hipStream_t)stream;
     const int Lp = (L + 31) & ~31;
     const float scale = 1.0f / sqrtf((float)dh);
+    if (sc_attn_bwd_cls(qkv, out, dout, lse, delta, dqkv, B, L, Lq, H, dh, causal, st)) {      // q_rows == 1
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     // 1) single-pass (non-causal, L <= 224): 232-256 us per ViT-B/16 layer; 2) persistent two-pass with loader waves
     // (also causal): 254 us; 3) one workgroup per head: 268-296 us.  The switches are read per call (tests select a path).
     const bool single_on = !(getenv("SC_ATTN_BWD1") && getenv("SC_ATTN_BWD1")[0] == '0');

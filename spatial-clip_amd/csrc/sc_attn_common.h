@@ -18,6 +18,10 @@ int sc_attn_bwd_single_pass(const void* qkv, const void* out, const void* dout, 
 int sc_attn_bwd_persistent(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            int B, int L, int Lq, int H, int dh, int causal, hipStream_t st);
 
+// sc_attention_cls.hip: backward for q_rows == 1 (class-token-only last block); 1 = launched, 0 = not this shape
+int sc_attn_bwd_cls(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+                    int L, int Lq, int H, int dh, int causal, hipStream_t st);
+
 namespace {
 
 constexpr int MAXL = 320;

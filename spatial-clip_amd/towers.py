@@ -170,13 +170,12 @@ class TransformerStack:
         ops.layernorm_bwd(dA_c, xmid, bf.get("c.m2", (B,), F32), bf.get("c.r2", (B,), F32),
                           s.p(self._n(i, "ln_2.weight")), dres_c, g1_c, g("ln_2.weight"), g("ln_2.bias"),
                           g("attn.out_proj.bias"), B, d, accumulate=True)
-        # attention branch: dO is non-zero on the CLS rows only (written through a strided view of a zeroed buffer)
+        # attention branch: only the CLS rows of dO exist (written through a strided view); sc_attn_bwd with q_rows = 1
+        # reads nothing else of dO / o and writes ALL of dqkv (zeros for the dq rows nobody consumed): no memsets
         dO = bf.get("dO", (M, d), BF16)
-        dO.zero_()
         ops.gemm(ops.NT, ops.EPI_BF16, g1_c, cp("attn.out_proj.weight").wb, dO.view(B, L * d)[:, :d], M=B, N=d, K=d)
         o_c = o.view(B, L * d)[:, :d]
         dqkv = bf.get(f"dqkv.{i & 1}", (M, 3 * d), BF16)
-        dqkv.zero_()
         ops.attn_bwd(qkv, o, dO, lse, B, L, H, dh, self.causal, dqkv=dqkv, delta=bf.get("delta", (B, H, L), F32),
                      q_rows=1)
 

@@ -160,8 +160,8 @@ def test_layernorm_fwd_bwd(rows, d):
 
 
 def test_attention_cls_query_only():
-    """q_rows = 1 (the last ViT block feeds only the CLS token on): outputs / dq of the other rows are not written, dk / dv
-    get the CLS query's contribution only, and dout of the unused rows (any finite value) does not matter."""
+    """q_rows = 1 (the last ViT block feeds only the CLS token on): outputs of the other rows are not written, their dq is
+    written as exact zeros, dk / dv get the CLS query's contribution only, and dout of the unused rows does not matter."""
     ops = _ops()
     B, L, H, dh = 3, 50, 2, 64
     d = H * dh
@@ -181,8 +181,29 @@ def test_attention_cls_query_only():
     dout_dev = dout.clone()
     dout_dev[keep] = 1.0e4                               # finite garbage: multiplied by exact zeros only
     out_in = out.clone(); out_in[keep.cuda()] = 0
-    dqkv = torch.zeros(B * L, 3 * d, dtype=torch.bfloat16, device="cuda")
+    dout_dev[keep] = float("nan")                        # the q_rows = 1 kernel does not even read the unused rows
+    dqkv = torch.full((B * L, 3 * d), 9.0, dtype=torch.bfloat16, device="cuda")     # no memset needed: every element is written
     ops.attn_bwd(qkv.cuda(), out_in, dout_dev.cuda(), lse, B, L, H, dh, False, dqkv=dqkv, q_rows=1)
+    torch.testing.assert_close(dqkv.float().cpu(), x.grad, atol=4e-2, rtol=4e-2)
+    assert bool((dqkv.cpu()[keep][:, :d] == 0).all())    # dq of the unconsumed queries: exact zeros
+
+
+@pytest.mark.parametrize("B,L,H,dh,causal", [(5, 197, 12, 64, False), (4, 77, 8, 64, True), (3, 320, 2, 32, False), (2, 2, 1, 64, False)])
+def test_attention_bwd_cls_kernel_shapes(B, L, H, dh, causal):
+    """q_rows = 1 backward (rank-one dK / dV, fp32 math) over head dims, the longest sequence, causal (query 0 sees key 0
+    only) and the shortest sequence, against autograd of the class-token outputs."""
+    ops = _ops()
+    d = H * dh
+    g = torch.Generator().manual_seed(L * 3 + dh)
+    qkv = bf(torch.randn(B * L, 3 * d, generator=g))
+    dout = bf(torch.randn(B * L, d, generator=g))
+    x = qkv.float().requires_grad_(True)
+    o_ref, _ = ref_attn(x, B, L, H, dh, causal)
+    cls = torch.arange(B) * L
+    (o_ref[cls] * dout.float()[cls]).sum().backward()
+    out, lse = ops.attn_fwd(qkv.cuda(), B, L, H, dh, causal)
+    dqkv = torch.full((B * L, 3 * d), 9.0, dtype=torch.bfloat16, device="cuda")
+    ops.attn_bwd(qkv.cuda(), out, dout.cuda(), lse, B, L, H, dh, causal, dqkv=dqkv, q_rows=1)
     torch.testing.assert_close(dqkv.float().cpu(), x.grad, atol=4e-2, rtol=4e-2)
 
 
