@@ -225,3 +225,31 @@ def test_rccl_one_rank_group_runs_every_collective_and_changes_nothing():
     assert res[True]["gathers"] == 6 and res[False]["gathers"] == 0
     assert res[True]["loss"] == res[False]["loss"]
     assert torch.equal(res[True]["w"], res[False]["w"])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bench.py launched the way the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N):
+# two ranks share the one GPU of the test box (LOCAL_RANK % device_count) over gloo; rank 0 prints ONE JSON line that
+# carries the true world size and the global batch, and a --gpus / WORLD_SIZE mismatch exits non-zero
+def test_bench_under_torchrun_two_ranks_prints_one_line():
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SC_DIST_BACKEND="gloo", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")]
+    args = ["--steps", "2", "--warmup", "1", "--model", "ViT-Ti-16-gene", "--batch", "16", "--n-genes", "512",
+            "--no-cpu-baseline", "--no-loss-delta", "--no-kernel-events"]
+    r = subprocess.run(base + ["--gpus", "2"] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_gpus_live"] == 2 and out["config"]["global_batch"] == 32
+    assert out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak" and out["value"] > 0
+    r = subprocess.run(base + ["--gpus", "4"] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
