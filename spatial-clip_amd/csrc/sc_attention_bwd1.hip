@@ -247,13 +247,13 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const bf16* __restrict__
                     }
                     pf[bt] = pack8(pr[0], pr[1]);
                     dsf[bt] = pack8(ds[0], ds[1]);
-                    // dS tile for the dQ product: row = key, 4 consecutive queries = 8 bytes, Img<32> swizzle
+                    // dS tile for the dQ product: row = key, 4 consecutive queries = 8 bytes (ds_tile_off: conflict-free)
                     union { bf16x8 v; u32x2 h[2]; } u;
                     u.v = dsf[bt];
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
                         const int row = bt * 16 + li, qc = a * 16 + 4 * lg;
-                        *reinterpret_cast<u32x2*>(scratch + Img<32>::off(row, qc >> 3) + ((qc >> 2) & 1) * 8) = u.h[a];
+                        *reinterpret_cast<u32x2*>(scratch + ds_tile_off(row, qc >> 3) + ((qc >> 2) & 1) * 8) = u.h[a];
                     }
                 }
                 // dV^T += dO^T . P ,  dK^T += Q^T . dS   (contraction over the 32 queries of the block)
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const bf16* __restrict__
                 // dQ^T[d][q] = K^T . dS^T over this wave's 32 keys: fragments before the hand-off, MFMAs + adds inside it
                 bf16x8 dst[2];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) dst[a] = frag_tr<32>(scratch, 0, a * 16, li, lg);
+                for (int a = 0; a < 2; ++a) dst[a] = frag_tr_ds(scratch, a * 16, li, lg);
                 // ordered hand-off: I am contributor number `step` of query block j
                 lds_wait_ge(turn, (unsigned)NB * (unsigned)i + (unsigned)step);
 #pragma unroll
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const bf16* __restrict__
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const f32x4 v = which ? dv[bt][dt] : dk[bt][dt] * scale;
-                    *reinterpret_cast<u32x2*>(scratch + Img<DH>::off(li, dt * 2 + (lg >> 1)) + (lg & 1) * 8) =
+                    *reinterpret_cast<u32x2*>(scratch + stage_off(li, dt * 2 + (lg >> 1)) + (lg & 1) * 8) =
                         sc_pack4(v[0], v[1], v[2], v[3]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(512) void attn_bwd1_kernel(const bf16* __restrict__
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int r = hf * 8 + (lane >> 3), ch = lane & 7;
-                    const u32x4 u = *reinterpret_cast<const u32x4*>(scratch + Img<DH>::off(r, ch));
+                    const u32x4 u = *reinterpret_cast<const u32x4*>(scratch + stage_off(r, ch));
                     const int key = kb + bt * 16 + r;
                     const unsigned off = key < L ? (unsigned)((((long long)b * L + key) * rs + (which + 1) * d + h * DH + ch * 8) * 2)
                                                  : 0xFFFFFFF0u;

@@ -124,14 +124,14 @@ __global__ __launch_bounds__(1024) void attn_bwd2_kernel(const bf16* __restrict_
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const f32x4 v = acc[dt] * mul;
-            *reinterpret_cast<u32x2*>(scratch + Img<DH>::off(li, dt * 2 + (lg >> 1)) + (lg & 1) * 8) = sc_pack4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<u32x2*>(scratch + stage_off(li, dt * 2 + (lg >> 1)) + (lg & 1) * 8) = sc_pack4(v[0], v[1], v[2], v[3]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int r = hf * 8 + (lane >> 3), ch = lane & 7;
-            const u32x4 u = *reinterpret_cast<const u32x4*>(scratch + Img<DH>::off(r, ch));
+            const u32x4 u = *reinterpret_cast<const u32x4*>(scratch + stage_off(r, ch));
             // the head's base goes into the VGPR offset, not the SGPR offset field: with a register soffset the compiler
             // assumes there is no "store data > 64 bits, then VALU write of the data registers" hazard and places no
             // wait state; on gfx950 the next VALU write did clobber the first data dword of some lanes (seen in the

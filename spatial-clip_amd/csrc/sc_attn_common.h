@@ -156,6 +156,27 @@ SC_DEVICE f32x4 exp2_affine(f32x4 x, float c, float b) {
     return (f32x4){fast_exp2(a[0]), fast_exp2(a[1]), fast_exp2(a[2]), fast_exp2(a[3])};
 }
 
+// ---- wave-private LDS tiles of the backward kernels, laid out for conflict-free 8-byte accumulator-layout writes
+// (PMC on the first versions: SQ_LDS_BANK_CONFLICT = 24 % / 13 % of SQ_LDS_IDX_ACTIVE with the image swizzle, which is
+// built for 16-byte row reads and leaves rows r and r + 8 on the same banks)
+// staging tile, 16 rows x 128 B: the eight rows that share a bank phase (r, r + 2, ...) get eight different chunk slots
+SC_DEVICE int stage_off(int row, int chunk16) { return row * 128 + ((chunk16 ^ ((row >> 1) & 7)) << 4); }
+// dS tile, 32 rows (keys) x 64 B (32 queries): rows r, r + 4, r + 8, r + 12 share a bank phase; slot permutation
+// {0, 2, 1, 3} of the row group keeps the transposed reads of two adjacent groups in different 32-byte windows
+SC_DEVICE int ds_tile_off(int row, int chunk16) {
+    const int g = (row >> 2) & 3;
+    return row * 64 + ((chunk16 ^ (((g & 1) << 1) | (g >> 1))) << 4);
+}
+// transposed fragment of the dS tile for the 16 columns [c0, c0 + 16): lane (g, i) gets tile[slot(g, j)][c0 + i]
+SC_DEVICE bf16x8 frag_tr_ds(const char* tile, int c0, int li, int lg) {
+    const int q = li >> 2, p = li & 3;
+    const int r1 = 4 * lg + q, r2 = r1 + 16;
+    const int ch = (c0 >> 3) + (p >> 1);
+    const bf16x4 lo = sc_lds_tr16(tile + ds_tile_off(r1, ch) + ((p & 1) << 3));
+    const bf16x4 hi = sc_lds_tr16(tile + ds_tile_off(r2, ch) + ((p & 1) << 3));
+    return sc_cat(lo, hi);
+}
+
 // ---- pieces of the persistent kernels (LDS-DMA loader / helper waves, LDS arrival counters)
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

@@ -1,5 +1,6 @@
 """Bitwise comparison of the persistent two-pass attention backward against the one-workgroup-per-head kernel (same
 arithmetic, so every element must be identical), four launches per shape."""
+import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import spatial_clip_amd  # noqa
 from spatial_clip_amd import ops
