@@ -37,6 +37,14 @@ SC_DEVICE int launder(int v) {
     return v;
 }
 
+#ifdef SC_ATTN_TRACE
+// debug build only (tools/attn_phase_trace.py): cycle stamps of workgroup 0, first 8 heads; [role][head][slot]
+__device__ unsigned long long g_trace[2 * 8 * 8];
+#define TR(role, slot) do { if (blockIdx.x == 0 && i < 8 && (threadIdx.x & 63) == 0) g_trace[(role) * 64 + i * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TR(role, slot) do {} while (0)
+#endif
+
 template <int NB, bool CAUSAL>
 __global__ __launch_bounds__(1024) void attn_bwd2_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
@@ -83,17 +91,22 @@ __global__ __launch_bounds__(1024) void attn_bwd2_kernel(const bf16* __restrict_
         wg_barrier();                                                       // A(0)
         for (int i = 0; head < nheads; ++i, head += gridDim.x) {
             const int b = head / H, h = head % H;
+            if (hw == 0) TR(1, 0);
             dma_image(qkv + (long long)b * L * rs + h * DH, rs, Qimg);
             dma_image(dout + (long long)b * L * d + h * DH, d, Gimg);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (hw == 0) TR(1, 1);
             wg_barrier();                                                   // B(i)
+            if (hw == 0) TR(1, 2);
             const int next = head + gridDim.x;
             if (next < nheads) {
                 lds_wait_ge(khoist, (unsigned)NW * (unsigned)(i + 1));      // every compute wave holds its K / V fragments
+                if (hw == 0) TR(1, 3);
                 const bf16* base = qkv + (long long)(next / H) * L * rs + (next % H) * DH;
                 dma_image(base + d, rs, Kimg);
                 dma_image(base + 2 * d, rs, Vimg);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (hw == 0) TR(1, 4);
             }
             wg_barrier();                                                   // A(i+1)
         }
@@ -170,6 +183,7 @@ __global__ __launch_bounds__(1024) void attn_bwd2_kernel(const bf16* __restrict_
     for (int i = 0; head < nheads; ++i, head += gridDim.x) {
         const unsigned b = (unsigned)(head / H), h = (unsigned)(head % H);
         const unsigned sdq = __builtin_amdgcn_readfirstlane((b * (unsigned)L * urs + h * DH) * 2u);     // byte offset of this head's dQ columns
+        if (wave == 0) TR(0, 0);
         // ---------------- pass A: dQ of my 16 queries (+ delta, lse2 into LDS for pass B)
         {
             const int lane = launder((int)(threadIdx.x & 63)), li = lane & 15, lg = lane >> 4, q = row0 + li;
@@ -226,9 +240,12 @@ __global__ __launch_bounds__(1024) void attn_bwd2_kernel(const bf16* __restrict_
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) dq[dt] = sc_mfma16(ktr[dt], dsf, dq[dt]);
             }
+            if (wave == 0) TR(0, 1);
             store_tile(dq, scale, sdq);
+            if (wave == 0) TR(0, 2);
         }
         wg_barrier();                                                       // B(i)
+        if (wave == 0) TR(0, 3);
         // ---------------- pass B: dK, dV of my 16 keys
         const int lane = launder((int)(threadIdx.x & 63)), li = lane & 15, lg = lane >> 4, q = row0 + li;
         bf16x8 kf[KS], vf[KS];
@@ -290,6 +307,7 @@ __global__ __launch_bounds__(1024) void attn_bwd2_kernel(const bf16* __restrict_
                 dk[dt] = sc_mfma16(frag_tr<DH>(Qimg, q0, dt * 16, li, lg), dsf, dk[dt]);
             }
         }
+        if (wave == 0) TR(0, 4);
         // next head's pass-A operands first (their latency hides behind the stores and the barrier), then this head's rows
         const int next = head + gridDim.x;
         load_ops(min(next, nheads - 1), ops);              // unconditional: keeps the operands dead during pass B
@@ -301,6 +319,7 @@ __global__ __launch_bounds__(1024) void attn_bwd2_kernel(const bf16* __restrict_
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(ops.qf[ks]), "+v"(ops.dof[ks]), "+v"(ops.of[ks]));
         asm volatile("" : "+v"(ops.l));
+        if (wave == 0) TR(0, 5);
         wg_barrier();                                                       // A(i+1)
     }
 }
@@ -332,6 +351,12 @@ void launch_bwd2(bool causal, int grid, int threads, size_t lds, hipStream_t st,
 }
 
 }  // namespace
+
+#ifdef SC_ATTN_TRACE
+extern "C" int sc_debug_attn_trace(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_trace), sizeof(g_trace)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // returns 1 if this kernel took the launch, 0 if the shape is outside its range (caller falls back)
 int sc_attn_bwd_persistent(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
