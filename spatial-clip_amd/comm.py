@@ -78,6 +78,16 @@ def init_from_env(backend: Optional[str] = None, expect_world: Optional[int] = N
                 if local_rank >= torch.cuda.device_count():
                     raise RuntimeError(f"LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPUs are visible")
                 kw["device_id"] = torch.device(f"cuda:{local_rank}")      # eager RCCL communicator on this GPU
+                # RCCL's kernels on high-priority streams: a bucket all-reduce / feature gather launched beside the
+                # backward should get its few CUs as soon as a GEMM workgroup retires, not after the queued chain
+                # kernels (SC_RCCL_HIGH_PRIO=0 keeps the default)
+                if os.environ.get("SC_RCCL_HIGH_PRIO", "1") == "1":
+                    try:
+                        opts = dist.ProcessGroupNCCL.Options()
+                        opts.is_high_priority_stream = True
+                        kw["pg_options"] = opts
+                    except (AttributeError, TypeError):
+                        pass
             dist.init_process_group(backend, rank=rank, world_size=W, **kw)
         elif dist.get_world_size() != W or dist.get_rank() != rank:
             raise RuntimeError(f"live process group is rank {dist.get_rank()}/{dist.get_world_size()} but the "
