@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-loss-delta", action="store_true")
+    ap.add_argument("--grad-checkpointing", action="store_true",
+                    help="activation recomputation (LayerNorm outputs, GELU output): configs[4] at 1024 pairs per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: e4m3 forward GEMMs of the transformer blocks (BASELINE configs[4]); backward stays bf16")
     args = ap.parse_args()
@@ -229,6 +231,8 @@ def main():
 
     n = net.SpatialClipNet(args.model, None, n_genes=args.n_genes, seed=0, precision=args.dtype)
     cfg = n.cfg
+    if args.grad_checkpointing:
+        n.model.set_grad_checkpointing(True)
     if args.loss == "clip":
         loss_fn = losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True)
     else:
@@ -391,7 +395,9 @@ def main():
                           f"{cfg.gene.width}, embed {cfg.embed_dim}), ") + (
                                       f"{cfg.vision.image_size}x{cfg.vision.image_size} tiles, local batch {B}, "
                                       f"{'ClipLoss' if args.loss == 'clip' else 'SpatialLoss(k=8)'} over global batch {G}, "
-                                      "fwd+bwd+grad-allreduce+clip+AdamW"), "global_batch": G,
+                                      "fwd+bwd+grad-allreduce+clip+AdamW" +
+                                      (", activation recomputation (LN outputs, GELU output)" if args.grad_checkpointing else "")),
+                          "global_batch": G,
                           "parallelism": f"dp{world}", "loss": float(loss.detach())},
                "n_gpus_live": dist.get_world_size() if world > 1 else 1,
                "loss_delta_vs_oracle": None if delta is None else delta["loss_delta_vs_oracle"],

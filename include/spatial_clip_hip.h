@@ -212,6 +212,11 @@ int sc_knn_alpha(const float* xy, int N, int K, int mode, float sigma, int* nbr_
 int sc_augment_tiles(const void* src_u8_hwc, int B, int H, int W, const float* params12, float* out_nchw, int S,
                      const float* mean3_host, const float* std3_host, void* stream);
 
+/* h = gelu(u) on contiguous bf16 (exact-erf GELU, the formula and input of the fused GEMM epilogue: bit-identical to the
+ * epilogue's second output).  Used by the activation-recomputation mode (open_clip's CLIP.set_grad_checkpointing,
+ * src/open_clip/model.py:313-315): the block's GELU output is not kept for the backward.  n % 8 == 0. */
+int sc_gelu_bf16(const void* u, void* h, long long n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ optimiser
  * clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (src/models/spatial_clip_module.py:138-158,
  * configs/optimizer/adamw.yaml, configs/trainer/default.yaml:19).  grad_scale = 1/world_size folds DDP's

@@ -3,6 +3,7 @@
 // One 64-lane wave owns one row; every access is a 16-byte (fp32x4) or 8-byte (bf16x4) vector.
 #include "sc_common.h"
 #include "sc_kernels.h"
+#include "sc_gemm_common.h"   // sc_gelu_fast: the GELU of the GEMM epilogues
 
 namespace {
 
@@ -189,6 +190,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
     if (rl == 0 && col < n) {
         const f32x4 s = sm[0][cq] + sm[1][cq] + sm[2][cq] + sm[3][cq];
         st4(partial + (long long)blockIdx.y * n + col, s);
+    }
+}
+
+
+// ------------------------------------------------------------------ h = gelu(u), bf16 -> bf16
+// The activation-recomputation mode (SpatialClipNet.set_grad_checkpointing) does not keep the GELU output of a block for
+// the backward; the c_proj weight gradient gets it back from the saved pre-activation u with the epilogue's own formula
+// on the epilogue's own input (the bf16-rounded u), i.e. bit-identical to what the forward wrote.
+__global__ __launch_bounds__(256) void gelu_bf16_kernel(const bf16* __restrict__ u, bf16* __restrict__ h, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(u + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_gelu_fast((float)v[e]);
+        *reinterpret_cast<bf16x8*>(h + i * 8) = o;
     }
 }
 
@@ -444,6 +460,16 @@ extern "C" int sc_cast_transpose_bf16(const float* src, void* dst, int rows, int
     SC_CHECK(rows > 0 && cols > 0 && ld_dst >= rows, "sc_cast_transpose_bf16: bad shape");
     dim3 grid((cols + 63) / 64, (rows + 63) / 64);
     cast_transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, (bf16*)dst, rows, cols, ld_dst);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_gelu_bf16(const void* u, void* h, long long n, void* stream) {
+    SC_CHECK(n > 0 && (n % 8) == 0, "sc_gelu_bf16: element count must be a positive multiple of 8 (n=%lld)", n);
+    const long long n8 = n / 8;
+    long long blocks = (n8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    gelu_bf16_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const bf16*)u, (bf16*)h, n8);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -119,6 +119,12 @@ class _ClipFacade:
             f = self._net.second.forward(text)
             return (f if normalize else self._net.second.raw_features()).clone()
 
+    def set_grad_checkpointing(self, enable: bool = True) -> None:
+        """CLIP.set_grad_checkpointing (src/open_clip/model.py:313-315).  Here: activation recomputation inside the
+        transformer stacks -- LayerNorm outputs and the GELU output are rebuilt in the backward instead of kept
+        (one third less saved activation memory; results bit-identical to the default mode)."""
+        self._net.set_grad_checkpointing(enable)
+
 
 class SpatialClipNet(torch.nn.Module):
     def __init__(self, model_name: str, pretrained: Optional[str] = None, aug_cfg: Optional[Any] = None,
@@ -162,6 +168,12 @@ class SpatialClipNet(torch.nn.Module):
             self._load_pretrained(pretrained)
 
     # ------------------------------------------------------------------ reference-facing helpers
+    def set_grad_checkpointing(self, enable: bool = True) -> None:
+        for tower in (self.vision, self.second):
+            stack = getattr(tower, "stack", None)
+            if stack is not None:
+                stack.set_grad_checkpointing(enable)
+
     def _load_pretrained(self, pretrained: str) -> None:
         if os.path.isfile(pretrained):        # local checkpoint path branch of factory.py:418-421
             sd = torch.load(pretrained, map_location="cpu")

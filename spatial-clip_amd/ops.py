@@ -148,6 +148,15 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows: int, d: int, ldx: Optiona
     return y
 
 
+def gelu_bf16(u: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """h = gelu(u) (bf16 -> bf16, contiguous), bit-identical to the GELU-pair GEMM epilogue's second output."""
+    _req(u, torch.bfloat16, "u"); _req(h, torch.bfloat16, "h")
+    if not (u.is_contiguous() and h.is_contiguous()) or u.numel() != h.numel():
+        raise ValueError("gelu_bf16: contiguous tensors of equal size required")
+    check(_lib.lib().sc_gelu_bf16(u.data_ptr(), h.data_ptr(), u.numel(), _stream()), "sc_gelu_bf16")
+    return h
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, colsum, rows: int, d: int, *,
                   accumulate: bool, lddy=None, ldx=None, lddres=None, lddbf=None, ws=None, defer_reduce: bool = False):
     """``defer_reduce``: leave the per-block partial sums of dgamma / dbeta / colsum in ``ws`` (caller-owned, at least

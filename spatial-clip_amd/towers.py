@@ -64,6 +64,20 @@ class TransformerStack:
         self.dh = width // heads
         self.bufs = _Bufs(store.device)
         self.fp8 = bool(getattr(store, "fp8", False))
+        # activation recomputation (set_grad_checkpointing): the LayerNorm outputs and the GELU output of a block are not
+        # kept for the backward (12 of the 36 d bytes a token saves per block); the backward rebuilds them, bit-identically,
+        # from the saved residual stream / pre-activation right before the weight-gradient GEMMs that read them
+        self.recompute = False
+
+    def set_grad_checkpointing(self, enable: bool = True) -> None:
+        self.recompute = bool(enable)
+
+    def _act(self, kind: str, i: int, shape) -> torch.Tensor:
+        """Buffer of a block's recomputable activation (a1 / a2 / h): one per block, or two rotating ones in
+        recomputation mode (the CLS-only last block keeps its own: it runs first in the backward, nothing to rebuild)."""
+        if self.recompute and not (self.cls_only_last and i == self.layers - 1):
+            return self.bufs.get(f"{kind}.rc{i & 1}", shape, BF16)
+        return self.bufs.get(f"{kind}.{i}", shape, BF16)
 
     def _linear_fwd(self, epi: int, x: torch.Tensor, name: str, out: torch.Tensor, *, M: int, N: int, K: int, **kw):
         """One forward Linear of a full-width block: bf16 MFMA GEMM, or (fp8 path) per-row e4m3 quantisation of the
@@ -95,7 +109,7 @@ class TransformerStack:
         self.x_in = [None] * self.layers
         for i in range(self.layers):
             self.x_in[i] = x
-            a1 = bf.get(f"a1.{i}", (M, d), BF16)
+            a1 = self._act("a1", i, (M, d))
             m1 = bf.get(f"m1.{i}", (M,), F32)
             r1 = bf.get(f"r1.{i}", (M,), F32)
             ops.layernorm_fwd(x, s.p(self._n(i, "ln_1.weight")), s.p(self._n(i, "ln_1.bias")), a1, m1, r1, M, d)
@@ -110,12 +124,12 @@ class TransformerStack:
             xmid = bf.get(f"xmid.{i}", (M, d), F32)
             self._linear_fwd(ops.EPI_F32_BIAS_RES, o, self._n(i, "attn.out_proj.weight"), xmid,
                              M=M, N=d, K=d, bias=s.p(self._n(i, "attn.out_proj.bias")), res=x)
-            a2 = bf.get(f"a2.{i}", (M, d), BF16)
+            a2 = self._act("a2", i, (M, d))
             m2 = bf.get(f"m2.{i}", (M,), F32)
             r2 = bf.get(f"r2.{i}", (M,), F32)
             ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2, m2, r2, M, d)
             u = bf.get(f"u.{i}", (M, mlp), BF16)
-            h = bf.get(f"h.{i}", (M, mlp), BF16)
+            h = self._act("h", i, (M, mlp))
             self._linear_fwd(ops.EPI_GELU_PAIR, a2, self._n(i, "mlp.c_fc.weight"), u,
                              M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)
             xo = bf.get(f"xout.{i}", (M, d), F32)
@@ -272,8 +286,8 @@ class TransformerStack:
         for i in reversed(range(top)):
             g = lambda leaf, i=i: s.g(self._n(i, leaf))
             cp = lambda leaf, i=i: s.copies[self._n(i, leaf)]
-            a1, qkv, o = bf.get(f"a1.{i}", (M, d), BF16), bf.get(f"qkv.{i}", (M, 3 * d), BF16), bf.get(f"o.{i}", (M, d), BF16)
-            a2, u, h = bf.get(f"a2.{i}", (M, d), BF16), bf.get(f"u.{i}", (M, mlp), BF16), bf.get(f"h.{i}", (M, mlp), BF16)
+            a1, qkv, o = self._act("a1", i, (M, d)), bf.get(f"qkv.{i}", (M, 3 * d), BF16), bf.get(f"o.{i}", (M, d), BF16)
+            a2, u, h = self._act("a2", i, (M, d)), bf.get(f"u.{i}", (M, mlp), BF16), self._act("h", i, (M, mlp))
             xmid = bf.get(f"xmid.{i}", (M, d), F32)
             lse = bf.get(f"lse.{i}", (B, H, L), F32)
             dU = bf.get(f"dU.{i & 1}", (M, mlp), BF16)
@@ -289,7 +303,13 @@ class TransformerStack:
                 ops.gemm(ops.TN, ops.EPI_F32, g0, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M, splitk=_splitk_for(d, mlp, M))
                 ops.gemm_wgrad_bias(dU, a2, g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), M=mlp, N=d, K=M,
                                     splitk=_splitk_for(mlp, d, M))
-            on_side(w_mlp, (g0, dU))
+            if self.recompute:          # rebuild h = gelu(u) and a2 = ln_2(xmid) for the two weight gradients
+                before_write(h)
+                ops.gelu_bf16(u, h)
+                before_write(a2)
+                ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
+                                  bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32), M, d)
+            on_side(w_mlp, (g0, dU, h, a2) if self.recompute else (g0, dU))
             ops.gemm(ops.NT, ops.EPI_BF16, dU, cp("mlp.c_fc.weight").wb, dA, M=M, N=d, K=mlp)
             # LN2 backward accumulates into the residual gradient; its column sum is out_proj.bias' gradient
             rpos = (rpos + 1) % 3
@@ -306,7 +326,11 @@ class TransformerStack:
                 ops.gemm(ops.TN, ops.EPI_F32, g1, o, g("attn.out_proj.weight"), M=d, N=d, K=M, splitk=_splitk_for(d, d, M))
                 ops.gemm_wgrad_bias(dqkv, a1, g("attn.in_proj_weight"), g("attn.in_proj_bias"), M=3 * d, N=d, K=M,
                                     splitk=_splitk_for(3 * d, d, M))
-            on_side(w_attn, (g1, dqkv))
+            if self.recompute:          # rebuild a1 = ln_1(x_in) for the in_proj weight gradient
+                before_write(a1)
+                ops.layernorm_fwd(self.x_in[i], s.p(self._n(i, "ln_1.weight")), s.p(self._n(i, "ln_1.bias")), a1,
+                                  bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32), M, d)
+            on_side(w_attn, (g1, dqkv, a1) if self.recompute else (g1, dqkv))
             ops.gemm(ops.NT, ops.EPI_BF16, dqkv, cp("attn.in_proj_weight").wb, dA, M=M, N=d, K=3 * d)
             # LN1 backward; its column sum is the previous block's c_proj.bias gradient
             prev_bias = s.g(self._n(i - 1, "mlp.c_proj.bias")) if i > 0 else None

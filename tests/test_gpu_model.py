@@ -436,3 +436,53 @@ def test_gene_transformer_three_training_steps_vs_oracle():
     for k in ("gene.proj", "gene.conv1.weight", "gene.transformer.resblocks.1.mlp.c_fc.weight", "gene.positional_embedding"):
         a, b = n.store.p(k).cpu(), tr.p[k].detach()
         assert float((a - b).abs().max()) < 2.5e-3, k
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_grad_checkpointing_is_bit_identical_and_saves_buffers(monkeypatch, overlap):
+    """set_grad_checkpointing (open_clip's CLIP API, src/open_clip/model.py:313-315) = activation recomputation: the
+    LayerNorm outputs and the GELU output of a block are rebuilt in the backward from the saved residual stream /
+    pre-activation with the forward's own kernels, so losses, gradients and two optimiser steps are bit-identical to the
+    default mode -- on both towers (ViT + gene transformer, 4 layers each), with and without the weight-gradient side
+    stream -- while the per-block a1 / a2 / h buffers are replaced by two rotating ones."""
+    import functools
+    data, losses, mc, module, net, optim = _pkg()
+    monkeypatch.setenv("SC_OVERLAP", overlap)
+    cfg, _ = genetr_cfgs(width=128, head_width=64, layers=4, image=48, patch=16, glayers=4, gwidth=64, ghead=32)
+    B = 24
+    res = {}
+    for ckpt in (False, True):
+        n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=5)
+        perturb(n)
+        if ckpt:
+            n.model.set_grad_checkpointing(True)
+        loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                     neighbor_alpha_scale=0.5, float32_logits=True)
+        m = module.SpatialClipLitModule(
+            n, loss_fn, functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+            functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+
+        class T:
+            max_steps, max_epochs, estimated_stepping_batches = 10, None, 10
+        m.trainer = T()
+        oc = m.configure_optimizers()
+        opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+        ls, g0 = [], None
+        for s in range(2):
+            b = data.synthetic_batch(B, 48, cfg.gene.n_genes, K=4, step=s)
+            loss = m.training_step({k: v.cuda() for k, v in b.items()}, s)
+            loss.backward()
+            if s == 0:
+                g0 = n.store.grad.detach().clone()
+            opt.step(grad_scale=1.0, max_norm=1.0)
+            sched.step()
+            ls.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        names = set(n.vision.stack.bufs._b)
+        res[ckpt] = (ls, g0.cpu(), n.store.master.detach().cpu(), names)
+    assert res[False][0] == res[True][0]
+    assert torch.equal(res[False][1], res[True][1]), "gradients differ under activation recomputation"
+    assert torch.equal(res[False][2], res[True][2]), "weights differ after two steps"
+    assert {"h.0", "a1.1", "a2.2"} <= res[False][3]
+    assert not ({"h.0", "h.1", "h.2", "a1.0", "a2.1"} & res[True][3]) and {"h.rc0", "h.rc1", "a1.rc0", "a2.rc1"} <= res[True][3]
+    assert "a1.3" in res[True][3]           # the CLS-only last block keeps its own LayerNorm output

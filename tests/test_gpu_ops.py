@@ -386,3 +386,22 @@ def test_pack_rows_round_trip():
     out2 = torch.zeros(B, D, device="cuda")
     ops.pack_rows(f, None, None, out2)
     assert torch.equal(out2, f)
+
+
+def test_gelu_bf16_matches_the_gemm_epilogue_bitwise():
+    """sc_gelu_bf16 rebuilds the GELU output from the saved pre-activation (activation recomputation): it must be the
+    GELU-pair GEMM epilogue's second output bit for bit, and the exact-erf GELU within bf16 rounding."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 300, 512, 128
+    a = bf(torch.randn(M, K, generator=g)).cuda()
+    w = bf(torch.randn(N, K, generator=g) * 0.3).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    u = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"); h = torch.empty_like(u)
+    ops.gemm(ops.NT, ops.EPI_GELU_PAIR, a, w, u, M=M, N=N, K=K, bias=bias, out2=h)
+    h2 = ops.gelu_bf16(u, torch.full_like(u, 3.0))
+    assert torch.equal(h, h2)
+    ref = torch.nn.functional.gelu(u.float().cpu())
+    torch.testing.assert_close(h2.float().cpu(), ref, atol=2e-2, rtol=1e-2)
+    with pytest.raises(Exception):
+        ops.gelu_bf16(u[:, :7].contiguous(), h[:, :7].contiguous())          # element count not a multiple of 8
