@@ -400,6 +400,7 @@ def main():
                           "global_batch": G,
                           "parallelism": f"dp{world}", "loss": float(loss.detach())},
                "n_gpus_live": dist.get_world_size() if world > 1 else 1,
+               "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                "loss_delta_vs_oracle": None if delta is None else delta["loss_delta_vs_oracle"],
                "max_abs_feature_delta": None if delta is None else delta["max_abs_feature_delta"],
                "parity": delta, "roofline": roofline, "cpu_baseline": cpu}
