@@ -944,7 +944,18 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
         g.slab_stride = (long long)g.M * g.N;
     }
     const int nblocks = g.ntm * g.ntn * splitk;
-    if (mode == SC_GEMM_TN) return launch_tn(g, nblocks, st);
+    if (mode == SC_GEMM_TN) {
+        // SC_GEMM_TN4W=1 selects the 4-wave kernel (128x128 per wave, a third fewer transposed LDS reads; sc_gemm4w.hip).
+        // Measured: +15 % at 4096^3 (L2-resident operands), +5 % on a ViT-B/16 weight-gradient shape run in a loop, but
+        // equal (+-3 %) on the step's sequence of four shapes with cold operands and 0.35 ms per step SLOWER inside the
+        // training step -- the token-major operand stream from HBM / L2, not the LDS issue rate, bounds these shapes.
+        const char* e4 = getenv("SC_GEMM_TN4W");
+        if (e4 && e4[0] == '1') {
+            const int rc4 = sc_gemm4w_tn(g, nblocks, st);
+            if (rc4 != 0) return rc4;
+        }
+        return launch_tn(g, nblocks, st);
+    }
     // persistent walk of the tile list for the store-only bf16 epilogues once there is more than one round of tiles
     static const bool persist = !(getenv("SC_GEMM_PERSIST") && getenv("SC_GEMM_PERSIST")[0] == '0');
     if (persist && splitk == 1 && nblocks >= 1024 && ktiles >= 3) {      // >= 4 rounds of tiles (measured: +7 % at 7 rounds, -3 % at 2.3)
