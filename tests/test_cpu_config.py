@@ -80,3 +80,13 @@ def test_reference_config_tree_composes(exp, monkeypatch):
         assert cfg.trainer.devices == 2 and cfg.data.batch_size == 1500
     assert H._locate(cfg.model.loss_fn._target_).__module__ == "spatial_clip_amd.losses"
     assert H._locate(cfg.trainer._target_).__name__ == "Trainer"
+
+
+def test_eval_recipe_composes(monkeypatch):
+    """configs/eval.yaml (the reference's evaluation recipe, configs/eval.yaml: task_name eval, mandatory ckpt_path)."""
+    monkeypatch.setenv("PROJECT_ROOT", "/tmp")
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import hydra_lite
+    cfg = hydra_lite.compose("eval.yaml", ["experiment=smoke_shards", "ckpt_path=/tmp/x.ckpt"])
+    assert cfg.task_name == "eval" and cfg.ckpt_path == "/tmp/x.ckpt"
+    assert cfg.model.net.model_name == "ViT-Ti-16-gene" and cfg.data.batch_size == 8

@@ -1,6 +1,8 @@
 """End-to-end GPU parity: HIP towers + fused contrastive head + fused AdamW against the fp32 CPU oracle on identical
 parameters and batches.  Tolerances: features <= 5e-3 abs (bf16 operands), loss <= 1e-3 (north-star), gradients
 <= 3 % of the tensor's max-abs (bf16 GEMM operands, fp32 accumulation)."""
+import os
+
 import pytest
 import torch
 
@@ -124,6 +126,27 @@ def test_train_entry_smoke_shards(monkeypatch):
     metrics = train.main(["experiment=smoke_shards"])
     assert "train/loss" in metrics and metrics["train/loss"] == metrics["train/loss"]          # finite
     assert "val/loss" in metrics and "test/loss" in metrics and 0.0 <= metrics["test/R@10"] <= 1.0
+
+
+def test_train_then_eval_entry_points_agree(monkeypatch, tmp_path):
+    """The reference's tests/test_eval.py::test_train_eval on this package's entry points: train one epoch with
+    test=True and checkpointing, then `eval` with last.ckpt -- the evaluation reproduces the training run's test
+    metrics from the file alone (fresh model object, weights from the checkpoint)."""
+    monkeypatch.setenv("PROJECT_ROOT", str(tmp_path))
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import eval as sc_eval, train
+    over = ["experiment=smoke_shards", "trainer.fast_dev_run=false", "trainer.max_epochs=1", "save_ckpt=true",
+            f"trainer.default_root_dir={tmp_path}", "test=true"]
+    tm = train.main(over)
+    assert "last.ckpt" in os.listdir(tmp_path / "checkpoints")
+    em = sc_eval.main(["experiment=smoke_shards", "trainer.fast_dev_run=false", f"trainer.default_root_dir={tmp_path}",
+                       f"ckpt_path={tmp_path / 'checkpoints' / 'last.ckpt'}"])
+    assert em["test/loss"] == em["test/loss"] and 0.0 <= em["test/R@10"] <= 1.0
+    best = [f for f in os.listdir(tmp_path / "checkpoints") if f != "last.ckpt"]
+    if not best:                         # train's test phase used the final weights: the numbers must coincide
+        assert abs(tm["test/loss"] - em["test/loss"]) < 1e-6 and abs(tm["test/R@10"] - em["test/R@10"]) < 1e-6
+    with pytest.raises(ValueError):
+        sc_eval.main(["experiment=smoke_shards"])                     # ckpt_path is mandatory (configs/eval.yaml)
 
 
 def test_vit_tiny_224_loss_within_north_star_tolerance():
