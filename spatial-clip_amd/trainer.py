@@ -61,7 +61,7 @@ class Trainer:
                  limit_train_batches: float = 1.0, limit_val_batches: float = 1.0, limit_test_batches: float = 1.0,
                  deterministic: bool = False, strategy: str = "auto", num_nodes: int = 1, sync_batchnorm: bool = False,
                  default_root_dir: Optional[str] = None, enable_checkpointing: bool = False, callbacks=None, logger=None,
-                 **unused):
+                 val_check_interval: Any = 1.0, **unused):
         if precision not in ("bf16-mixed", "bf16", "32", "32-true", 32):
             raise ValueError(f"precision {precision!r}: the HIP path computes bf16 GEMMs with fp32 accumulation")
         if accelerator == "cpu":
@@ -74,6 +74,12 @@ class Trainer:
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.limit_test_batches = limit_test_batches
         self.log_every_n_steps = log_every_n_steps
+        # Lightning semantics: validate after every n-th epoch; val_check_interval = fraction of an epoch (float <= 1.0) or a
+        # number of training batches (int) between validation runs inside an epoch (tests/test_train.py of the reference)
+        self.check_val_every_n_epoch = max(1, int(check_val_every_n_epoch or 1))
+        if isinstance(val_check_interval, float) and not 0.0 < val_check_interval <= 1.0:
+            raise ValueError(f"val_check_interval={val_check_interval}: a float must lie in (0, 1]")
+        self.val_check_interval = val_check_interval
         self.devices, self.strategy, self.num_nodes = devices, strategy, num_nodes
         self.default_root_dir = default_root_dir
         self.global_step = 0
@@ -96,6 +102,28 @@ class Trainer:
         self.checkpoint_callback: Optional[CheckpointCallback] = None
         if enable_checkpointing and default_root_dir and not fast_dev_run:
             self.checkpoint_callback = CheckpointCallback(os.path.join(str(default_root_dir), "checkpoints"))
+
+    def _validate(self, model, datamodule) -> Dict[str, float]:
+        """One pass over the validation loader: val/loss, the module's retrieval metrics, the zero-shot metric if a
+        gene bank is configured (src/models/spatial_clip_module.py:104-136)."""
+        val = datamodule.val_dataloader()
+        n_val = self._limit(len(val), self.limit_val_batches)
+        model.val_metrics.reset()
+        model.on_validation_start()
+        if model.zero_shot_metric:
+            model.zero_shot_metric.reset()
+        vl, out = [], {}
+        for i, batch in enumerate(val):
+            if i >= n_val:
+                break
+            model.validation_step(_to_device(batch, model.device), i)
+            vl.append(model.logged["val/loss"])
+        if vl:
+            out["val/loss"] = float(torch.stack(vl).mean())
+            out.update(model.val_metrics.compute())
+            if model.zero_shot_metric and model.gene_bank_embeddings is not None:
+                out["val/zero_shot_pcc"] = model.zero_shot_metric.compute()
+        return out
 
     def _limit(self, n: int, frac) -> int:
         if self.fast_dev_run:
@@ -124,6 +152,10 @@ class Trainer:
         rank, W = comm.world()
         reducer = comm.GradBucketReducer(model.net.store.grad)
         model.net.grad_bucket_hook = reducer.bucket_ready if comm.is_dist() else None
+        vci = self.val_check_interval
+        val_every = 0 if self.fast_dev_run else (int(vci) if isinstance(vci, int) and not isinstance(vci, bool)
+                                                 else (max(1, int(n_train * vci)) if vci < 1.0 else 0))
+        self.val_runs = 0
         for epoch in range(start_epoch, epochs):
             self.current_epoch = epoch
             model.train_metrics.reset()
@@ -145,27 +177,18 @@ class Trainer:
                 self.global_step += 1
                 if self.global_step % self.log_every_n_steps == 0 or self.fast_dev_run:
                     self.history.append({"step": self.global_step, "train/loss": float(loss.detach())})
+                if val_every and (i + 1) % val_every == 0 and (i + 1) < n_train \
+                        and (epoch + 1) % self.check_val_every_n_epoch == 0:
+                    self.history.append({"step": self.global_step, "epoch": epoch, **self._validate(model, datamodule)})
+                    self.val_runs += 1
             torch.cuda.synchronize()
             rec = {"epoch": epoch, "time_s": time.time() - t0, **model.train_metrics.compute()}
-            if self.history and "train/loss" in self.history[-1]:
-                rec["train/loss"] = self.history[-1]["train/loss"]
-            val = datamodule.val_dataloader()
-            n_val = self._limit(len(val), self.limit_val_batches)
-            model.val_metrics.reset()
-            model.on_validation_start()
-            if model.zero_shot_metric:
-                model.zero_shot_metric.reset()
-            vl = []
-            for i, batch in enumerate(val):
-                if i >= n_val:
-                    break
-                model.validation_step(_to_device(batch, model.device), i)
-                vl.append(model.logged["val/loss"])
-            if vl:
-                rec["val/loss"] = float(torch.stack(vl).mean())
-                rec.update(model.val_metrics.compute())
-                if model.zero_shot_metric and model.gene_bank_embeddings is not None:
-                    rec["val/zero_shot_pcc"] = model.zero_shot_metric.compute()
+            last_train = next((h["train/loss"] for h in reversed(self.history) if "train/loss" in h), None)
+            if last_train is not None:
+                rec["train/loss"] = last_train
+            if (epoch + 1) % self.check_val_every_n_epoch == 0:
+                rec.update(self._validate(model, datamodule))
+                self.val_runs += 1
             self.history.append(rec)
             self._checkpoint_epoch(model, opt, sched, rec)
         self.callback_metrics = {k: v for k, v in self.history[-1].items() if isinstance(v, float)} if self.history else {}

@@ -149,6 +149,26 @@ def test_train_then_eval_entry_points_agree(monkeypatch, tmp_path):
         sc_eval.main(["experiment=smoke_shards"])                     # ckpt_path is mandatory (configs/eval.yaml)
 
 
+def test_train_double_val_loop_and_every_other_epoch(monkeypatch, tmp_path):
+    """The reference's tests/test_train.py::test_train_epoch_double_val_loop (trainer.val_check_interval=0.5: a second
+    validation run in the middle of the epoch) and Lightning's check_val_every_n_epoch through the entry point."""
+    monkeypatch.setenv("PROJECT_ROOT", str(tmp_path))
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import hydra_lite, train
+    base = ["experiment=smoke_shards", "trainer.fast_dev_run=false", "data.steps_per_epoch=4", "test=false"]
+    _, obj = train.train(hydra_lite.compose("train.yaml", base + ["trainer.max_epochs=1", "trainer.val_check_interval=0.5"]))
+    tr = obj["trainer"]
+    assert tr.val_runs == 2 and tr.global_step == 4
+    mid = [h for h in tr.history if "val/loss" in h and "time_s" not in h]
+    assert len(mid) == 1 and mid[0]["step"] == 2 and "val/loss" in tr.callback_metrics
+    _, obj = train.train(hydra_lite.compose("train.yaml", base + ["trainer.max_epochs=2", "trainer.check_val_every_n_epoch=2"]))
+    tr = obj["trainer"]
+    epochs = [h for h in tr.history if "time_s" in h]
+    assert tr.val_runs == 1 and "val/loss" not in epochs[0] and "val/loss" in epochs[1]
+    with pytest.raises(ValueError):
+        train.train(hydra_lite.compose("train.yaml", base + ["trainer.val_check_interval=1.5"]))
+
+
 def test_vit_tiny_224_loss_within_north_star_tolerance():
     """ViT-Ti/16 at 224 px, 12 layers, batch 32: |loss - fp32 oracle| <= 1e-3 (the north-star bound)."""
     data, losses, mc, module, net, optim = _pkg()
