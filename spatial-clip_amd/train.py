@@ -32,7 +32,9 @@ def train(cfg) -> Tuple[Dict[str, Any], Dict[str, Any]]:
     datamodule.tokenizer = model.net.tokenizer
     if "save_ckpt" in cfg and isinstance(cfg.get("trainer"), dict):
         cfg.trainer["enable_checkpointing"] = bool(cfg.save_ckpt)          # src/train.py:92-99
-    trainer = hydra_lite.instantiate(cfg.trainer)
+    # callbacks stay configuration (model_checkpoint / early_stopping keys of configs/callbacks/*.yaml), read by the Trainer
+    cbs = cfg.get("callbacks")
+    trainer = hydra_lite.instantiate(cfg.trainer, callbacks=dict(cbs) if isinstance(cbs, dict) else None)
     objects = {"cfg": cfg, "datamodule": datamodule, "model": model, "trainer": trainer}
     metrics: Dict[str, Any] = {}
     if cfg.get("train", True):

@@ -99,9 +99,26 @@ class Trainer:
             comm.init_from_env(expect_world=want)
         self.rank, self.world_size = comm.world()
         self.is_global_zero = self.rank == 0
+        # callbacks: the reference instantiates Lightning callbacks from cfg.callbacks (src/train.py:77-99,
+        # configs/callbacks/default.yaml).  Here the two that change what a run produces are read from the same config
+        # keys: model_checkpoint {dirpath, monitor, mode} and early_stopping {monitor, mode, patience, min_delta};
+        # model_summary / rich_progress_bar are presentation only and ignored.
+        cbs = callbacks if isinstance(callbacks, dict) else {}
+        mc = cbs.get("model_checkpoint") if isinstance(cbs.get("model_checkpoint"), dict) else None
+        es = cbs.get("early_stopping") if isinstance(cbs.get("early_stopping"), dict) else None
         self.checkpoint_callback: Optional[CheckpointCallback] = None
-        if enable_checkpointing and default_root_dir and not fast_dev_run:
-            self.checkpoint_callback = CheckpointCallback(os.path.join(str(default_root_dir), "checkpoints"))
+        if enable_checkpointing and not fast_dev_run and (default_root_dir or (mc and mc.get("dirpath"))):
+            dirpath = (mc or {}).get("dirpath") or os.path.join(str(default_root_dir), "checkpoints")
+            self.checkpoint_callback = CheckpointCallback(str(dirpath), monitor=(mc or {}).get("monitor") or "val/R@1",
+                                                          mode=(mc or {}).get("mode") or "max")
+        self.early_stopping = None
+        if es and es.get("monitor") and not fast_dev_run:
+            if es.get("mode", "min") not in ("min", "max"):
+                raise ValueError(f"early_stopping.mode={es.get('mode')!r}: 'min' or 'max'")
+            self.early_stopping = {"monitor": es["monitor"], "mode": es.get("mode", "min"),
+                                   "patience": int(es.get("patience", 3)), "min_delta": float(es.get("min_delta", 0.0)),
+                                   "best": None, "wait": 0}
+        self.should_stop = False
 
     def _validate(self, model, datamodule) -> Dict[str, float]:
         """One pass over the validation loader: val/loss, the module's retrieval metrics, the zero-shot metric if a
@@ -191,9 +208,27 @@ class Trainer:
                 self.val_runs += 1
             self.history.append(rec)
             self._checkpoint_epoch(model, opt, sched, rec)
+            if self._early_stop(rec):
+                break
         self.callback_metrics = {k: v for k, v in self.history[-1].items() if isinstance(v, float)} if self.history else {}
 
     # ------------------------------------------------------------------ checkpoints (reference state_dict names)
+    def _early_stop(self, rec: Dict[str, Any]) -> bool:
+        """lightning.pytorch.callbacks.EarlyStopping on the epoch's validation record: stop after `patience` validated
+        epochs without an improvement of more than min_delta (every rank sees the same all-reduced metrics)."""
+        es = self.early_stopping
+        if es is None or es["monitor"] not in rec:
+            return False
+        v = float(rec[es["monitor"]])
+        better = es["best"] is None or (v > es["best"] + es["min_delta"] if es["mode"] == "max"
+                                        else v < es["best"] - es["min_delta"])
+        if better:
+            es["best"], es["wait"] = v, 0
+        else:
+            es["wait"] += 1
+        self.should_stop = es["wait"] >= es["patience"]
+        return self.should_stop
+
     def _checkpoint_epoch(self, model, opt, sched, rec: Dict[str, Any]) -> None:
         cb = self.checkpoint_callback
         if cb is None:

@@ -215,3 +215,26 @@ def test_gene_transformer_registry_and_parameter_layout():
     f.sum().backward()
     assert all(torch.isfinite(p[k].grad).all() and p[k].grad.abs().sum() > 0 for k in p if k.startswith("gene."))
     assert float(p["gene.conv1.weight"].grad.abs().sum()) > 0
+
+
+def test_trainer_reads_checkpoint_and_early_stopping_config(tmp_path):
+    """cfg.callbacks of the reference (configs/callbacks/default.yaml: model_checkpoint {dirpath, monitor, mode},
+    early_stopping {monitor, mode, patience}) is read as configuration; Lightning's EarlyStopping rule on epoch records."""
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd.trainer import Trainer
+    cbs = {"model_checkpoint": {"_target_": "lightning.pytorch.callbacks.ModelCheckpoint", "dirpath": str(tmp_path / "ck"),
+                                "monitor": "val/loss", "mode": "min", "save_last": True},
+           "early_stopping": {"_target_": "lightning.pytorch.callbacks.EarlyStopping", "monitor": "val/R@1", "mode": "max",
+                              "patience": 2, "min_delta": 0.01},
+           "model_summary": {"max_depth": -1}}
+    tr = Trainer(max_epochs=5, enable_checkpointing=True, callbacks=cbs)
+    cb = tr.checkpoint_callback
+    assert cb.dirpath == str(tmp_path / "ck") and cb.monitor == "val/loss" and cb.mode == "min"
+    assert cb.is_better(1.0) and not (setattr(cb, "best_model_score", 0.5) or cb.is_better(0.7))
+    seq = [0.10, 0.20, 0.205, 0.19, 0.5]                       # +0.005 and -0.015 do not beat min_delta: stop at the 4th
+    stops = [tr._early_stop({"val/R@1": v}) for v in seq[:4]]
+    assert stops == [False, False, False, True] and tr.should_stop
+    assert not Trainer(max_epochs=1)._early_stop({"val/R@1": 0.1})                       # no early_stopping configured
+    assert Trainer(max_epochs=1, enable_checkpointing=True).checkpoint_callback is None  # nowhere to write
+    d = Trainer(max_epochs=1, enable_checkpointing=True, default_root_dir=str(tmp_path)).checkpoint_callback
+    assert d.dirpath == str(tmp_path / "checkpoints") and d.monitor == "val/R@1" and d.mode == "max"

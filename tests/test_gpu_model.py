@@ -169,6 +169,27 @@ def test_train_double_val_loop_and_every_other_epoch(monkeypatch, tmp_path):
         train.train(hydra_lite.compose("train.yaml", base + ["trainer.val_check_interval=1.5"]))
 
 
+def test_early_stopping_and_checkpoint_monitor_from_callbacks_config(monkeypatch, tmp_path):
+    """callbacks=default through the entry point: the checkpoint directory / monitor come from cfg.callbacks, and an
+    early_stopping rule that can never be satisfied (val/loss must RISE by 10 per epoch) ends the run after `patience`
+    validated epochs instead of max_epochs."""
+    monkeypatch.setenv("PROJECT_ROOT", str(tmp_path))
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import hydra_lite, train
+    cfg = hydra_lite.compose("train.yaml", ["experiment=smoke_shards", "callbacks=default", "trainer.fast_dev_run=false",
+                                            "trainer.max_epochs=6", "save_ckpt=true", "test=false",
+                                            f"callbacks.model_checkpoint.dirpath={tmp_path / 'ck'}",
+                                            "callbacks.model_checkpoint.monitor=val/loss", "callbacks.model_checkpoint.mode=min",
+                                            "callbacks.early_stopping.monitor=val/loss", "callbacks.early_stopping.mode=max",
+                                            "callbacks.early_stopping.min_delta=10.0", "callbacks.early_stopping.patience=2"])
+    _, obj = train.train(cfg)
+    tr = obj["trainer"]
+    assert tr.should_stop and tr.current_epoch == 2                   # epochs 0 (baseline), 1, 2 (two without improvement)
+    files = sorted(os.listdir(tmp_path / "ck"))
+    assert "last.ckpt" in files and tr.checkpoint_callback.monitor == "val/loss"
+    assert tr.checkpoint_callback.best_model_path and os.path.basename(tr.checkpoint_callback.best_model_path) in files
+
+
 def test_vit_tiny_224_loss_within_north_star_tolerance():
     """ViT-Ti/16 at 224 px, 12 layers, batch 32: |loss - fp32 oracle| <= 1e-3 (the north-star bound)."""
     data, losses, mc, module, net, optim = _pkg()
