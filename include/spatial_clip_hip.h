@@ -217,6 +217,23 @@ int sc_augment_tiles(const void* src_u8_hwc, int B, int H, int W, const float* p
  * src/open_clip/model.py:313-315): the block's GELU output is not kept for the backward.  n % 8 == 0. */
 int sc_gelu_bf16(const void* u, void* h, long long n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ RCCL
+ * The collectives of the data-parallel step on a caller-supplied HIP stream (enqueue only, never a host wait); RCCL is
+ * resolved at run time, reusing the instance the process already loaded.  One process per GPU.
+ * sc_comm_unique_id: rank 0 fills 128 bytes that the caller distributes (any side channel); sc_comm_init: collective
+ * over `world` processes, binds to the current HIP device, returns an opaque handle (0 on error); sc_comm_destroy.
+ * sc_allgather_feats_async: recv[world * bytes_per_rank] = rank-major concatenation of every rank's send block -- the
+ * packed features (+ tile ids) of gather_features (src/open_clip/loss.py:21-65, src/models/components/losses.py:58-68).
+ * sc_reduce_scatter_grads_async: recv[floats_per_rank] = sum over ranks of block `rank` of send[world * floats_per_rank]
+ * (backward of the gather with gather_with_grad=True).  sc_allreduce_sum_async: in-place sum of a gradient bucket
+ * (DDP's gradient reduction, configs/trainer/ddp.yaml; the 1/world factor is folded into sc_adamw_step). */
+int sc_comm_unique_id(void* id_out_128);
+long long sc_comm_init(const void* id_128, int rank, int world);
+int sc_comm_destroy(void* comm);
+int sc_allgather_feats_async(void* comm, const void* send, void* recv, long long bytes_per_rank, void* stream);
+int sc_reduce_scatter_grads_async(void* comm, const float* send, float* recv, long long floats_per_rank, void* stream);
+int sc_allreduce_sum_async(void* comm, float* buf, long long n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ optimiser
  * clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (src/models/spatial_clip_module.py:138-158,
  * configs/optimizer/adamw.yaml, configs/trainer/default.yaml:19).  grad_scale = 1/world_size folds DDP's

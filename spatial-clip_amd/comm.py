@@ -18,6 +18,10 @@ Collectives of the path:
   C4     GradBucketReducer   bucketed SUM all-reduce of the flat fp32 gradient buffer, launched per layer while
                            backward is still running (RCCL runs on its own stream; the 1/world_size of DDP's mean
                            is folded into the optimiser's grad_scale)
+``SC_COMM_NATIVE=1`` routes the three data-path collectives through the kernel library's own RCCL entry points
+(``sc_allgather_feats_async`` / ``sc_reduce_scatter_grads_async`` / ``sc_allreduce_sum_async`` on explicit HIP streams,
+include/spatial_clip_hip.h) instead of ``torch.distributed``; the process group is then only the bootstrap channel for the
+128-byte communicator id.
 All functions are device-agnostic (CUDA/HIP or CPU tensors) and degrade to no-ops at world_size 1
 (``SC_FORCE_DIST=1`` keeps the collective code path alive on a 1-rank group: used to exercise RCCL on a 1-GPU box)."""
 from __future__ import annotations
@@ -89,13 +93,72 @@ def init_from_env(backend: Optional[str] = None, expect_world: Optional[int] = N
                     except (AttributeError, TypeError):
                         pass
             dist.init_process_group(backend, rank=rank, world_size=W, **kw)
+            if backend == "nccl" and os.environ.get("SC_COMM_NATIVE", "0") == "1":
+                global _native
+                _native = NativeComm(rank, W, torch.device(f"cuda:{local_rank}"))
         elif dist.get_world_size() != W or dist.get_rank() != rank:
             raise RuntimeError(f"live process group is rank {dist.get_rank()}/{dist.get_world_size()} but the "
                                f"environment says {rank}/{W}")
     return rank, local_rank, W
 
 
+class NativeComm:
+    """RCCL communicator owned through the C ABI (sc_comm_*): collectives are enqueued on a caller-chosen HIP stream by
+    the kernel library itself, no torch.distributed object on the data path."""
+
+    def __init__(self, rank: int, world_size: int, device: torch.device):
+        import ctypes
+        from . import _lib
+        self._l, self._check = _lib.lib(), _lib.check
+        self.rank, self.world_size, self.device = rank, world_size, device
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            self._check(self._l.sc_comm_unique_id(buf), "sc_comm_unique_id")
+        box = [buf.raw if rank == 0 else None]
+        if world_size > 1:
+            dist.broadcast_object_list(box, src=0)          # bootstrap: the existing process group carries the id
+        with torch.cuda.device(device):
+            self.handle = self._l.sc_comm_init(box[0], rank, world_size)
+        if not self.handle:
+            raise RuntimeError("sc_comm_init failed: " + self._l.sc_last_error().decode())
+        self.stream = torch.cuda.Stream(device=device, priority=-1)     # gradient buckets travel here
+        self.launched = 0
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor, stream) -> None:
+        self._check(self._l.sc_allgather_feats_async(self.handle, send.data_ptr(), recv.data_ptr(),
+                                                     send.numel() * send.element_size(), stream.cuda_stream),
+                    "sc_allgather_feats_async")
+        self.launched += 1
+
+    def reduce_scatter(self, send: torch.Tensor, recv: torch.Tensor, stream) -> None:
+        self._check(self._l.sc_reduce_scatter_grads_async(self.handle, send.data_ptr(), recv.data_ptr(), recv.numel(),
+                                                          stream.cuda_stream), "sc_reduce_scatter_grads_async")
+        self.launched += 1
+
+    def all_reduce(self, buf: torch.Tensor, stream) -> None:
+        self._check(self._l.sc_allreduce_sum_async(self.handle, buf.data_ptr(), buf.numel(), stream.cuda_stream),
+                    "sc_allreduce_sum_async")
+        self.launched += 1
+
+    def destroy(self) -> None:
+        if self.handle:
+            torch.cuda.synchronize(self.device)
+            self._l.sc_comm_destroy(self.handle)
+            self.handle = 0
+
+
+_native: Optional[NativeComm] = None
+
+
+def native() -> Optional[NativeComm]:
+    return _native
+
+
 def shutdown() -> None:
+    global _native
+    if _native is not None:
+        _native.destroy()
+        _native = None
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
@@ -139,7 +202,10 @@ def gather_packed(image_features: torch.Tensor, text_features: torch.Tensor,
         packed[:, 2 * D:2 * D + 2].view(torch.int64).copy_(image_tile_ids.view(B, 1))
         packed[:, 2 * D + 2:2 * D + 4].view(torch.int64).copy_(text_tile_ids.view(B, 1))
     out = torch.empty((W * B, cols), dtype=torch.float32, device=packed.device)
-    dist.all_gather_into_tensor(out, packed)
+    if _native is not None and packed.is_cuda:
+        _native.all_gather(packed, out, torch.cuda.current_stream(packed.device))
+    else:
+        dist.all_gather_into_tensor(out, packed)
     all_i = out[:, :D].contiguous()
     all_t = out[:, D:2 * D].contiguous()
     if with_ids:
@@ -204,8 +270,11 @@ class FeatureGather:
         self.stream.wait_event(ready)               # the features are final on the compute stream
         with torch.cuda.stream(self.stream):
             _pack(feat, ids_i, ids_t, send)
-            work = dist.all_gather_into_tensor(recv, send, async_op=True)
-            work.wait()                             # nccl: the communication stream waits for RCCL's stream (no host block)
+            if _native is not None:
+                _native.all_gather(send, recv, self.stream)     # RCCL's kernel is enqueued on the communication stream itself
+            else:
+                work = dist.all_gather_into_tensor(recv, send, async_op=True)
+                work.wait()                         # nccl: the communication stream waits for RCCL's stream (no host block)
             done = torch.cuda.Event()
             done.record(self.stream)
         self._done[which] = done
@@ -243,7 +312,10 @@ def reduce_scatter_sum(full: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(full, op=dist.ReduceOp.SUM)
         return full[rank * B:(rank + 1) * B].clone()
     out = torch.empty((B,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
-    dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM)
+    if _native is not None and full.is_cuda and full.dtype == torch.float32:
+        _native.reduce_scatter(full, out, torch.cuda.current_stream(full.device))
+    else:
+        dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM)
     return out
 
 
@@ -276,9 +348,22 @@ class GradBucketReducer:
             self._launch(plo, phi)
             self.pending = None
 
+    def _reduce(self, lo: int, hi: int):
+        """Enqueue the SUM all-reduce of flat[lo:hi] behind the caller's stream; returns what finish() waits on."""
+        if _native is not None and self.flat.is_cuda:
+            cur = torch.cuda.current_stream(self.flat.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            _native.stream.wait_event(ready)
+            _native.all_reduce(self.flat[lo:hi], _native.stream)
+            done = torch.cuda.Event()
+            done.record(_native.stream)
+            return done
+        return dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+
     def _launch(self, lo: int, hi: int) -> None:
         self.launched.append((lo, hi))
-        self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self.works.append(self._reduce(lo, hi))
 
     def finish(self) -> None:
         if not is_dist():
@@ -293,8 +378,11 @@ class GradBucketReducer:
             pos = 0
             for lo, hi in done + [(self.flat.numel(), self.flat.numel())]:
                 if lo > pos:
-                    self.works.append(dist.all_reduce(self.flat[pos:lo], op=dist.ReduceOp.SUM, async_op=True))
+                    self.works.append(self._reduce(pos, lo))
                 pos = max(pos, hi)
         for w in self.works:
-            w.wait()
+            if isinstance(w, torch.cuda.Event):
+                torch.cuda.current_stream(self.flat.device).wait_event(w)
+            else:
+                w.wait()
         self.works, self.launched = [], []

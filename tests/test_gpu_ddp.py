@@ -173,12 +173,12 @@ def test_train_entry_point_two_ranks_overlapped_gather_is_bit_identical():
 # RCCL itself: a ONE-rank nccl group with the distributed code path forced on (SC_FORCE_DIST=1) runs every collective
 # of the step -- packed all-gathers on the communication stream, reduce_scatter_tensor, bucketed async all-reduce -- on
 # the real RCCL backend; at world size 1 they are identities, so the result must equal the plain single-process run
-def _rccl_worker(rank, world, port, force, ret):
+def _rccl_worker(rank, world, port, force, ret, native=False):
     import sys
     sys.path.insert(0, ROOT)
     import functools
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "LOCAL_RANK": "0",
-                       "WORLD_SIZE": "1", "SC_FORCE_DIST": "1" if force else "0"})
+                       "WORLD_SIZE": "1", "SC_FORCE_DIST": "1" if force else "0", "SC_COMM_NATIVE": "1" if native else "0"})
     import spatial_clip_amd  # noqa: F401
     from spatial_clip_amd import comm, data, losses, model_configs as mc, module, net, optim
     comm.init_from_env()
@@ -210,9 +210,13 @@ def _rccl_worker(rank, world, port, force, ret):
         sched.step()
         ls.append(float(loss.detach()))
     torch.cuda.synchronize()
-    ret[force] = {"w": n.store.master.detach().cpu(), "loss": ls,
-                  "gathers": 0 if m._feature_gather is None else m._feature_gather.launched}
+    nat = comm.native()
+    assert (nat is not None) == bool(native and force)
+    ret["native" if native else force] = {"w": n.store.master.detach().cpu(), "loss": ls,
+                                          "gathers": 0 if m._feature_gather is None else m._feature_gather.launched,
+                                          "native_calls": 0 if nat is None else nat.launched}
     comm.shutdown()
+    assert comm.native() is None
 
 
 def test_rccl_one_rank_group_runs_every_collective_and_changes_nothing():
@@ -221,10 +225,16 @@ def test_rccl_one_rank_group_runs_every_collective_and_changes_nothing():
         ret = mgr.dict()
         mp.spawn(_rccl_worker, args=(1, 29751, True, ret), nprocs=1, join=True)
         mp.spawn(_rccl_worker, args=(1, 29752, False, ret), nprocs=1, join=True)
+        mp.spawn(_rccl_worker, args=(1, 29753, True, ret, True), nprocs=1, join=True)
         res = dict(ret)
     assert res[True]["gathers"] == 6 and res[False]["gathers"] == 0
     assert res[True]["loss"] == res[False]["loss"]
     assert torch.equal(res[True]["w"], res[False]["w"])
+    # the same step with the collectives issued by the kernel library's own RCCL entry points (SC_COMM_NATIVE=1:
+    # sc_comm_init + sc_allgather_feats_async / sc_reduce_scatter_grads_async / sc_allreduce_sum_async on explicit streams)
+    nat = res["native"]
+    assert nat["gathers"] == 6 and nat["native_calls"] >= 6 + 3 + 3          # gathers + reduce-scatters + >= 1 bucket per step
+    assert nat["loss"] == res[False]["loss"] and torch.equal(nat["w"], res[False]["w"])
 
 
 # ----------------------------------------------------------------------------------------------------------------------
