@@ -5,8 +5,7 @@
 //     dK[k] = dS[k] q0 / sqrt(dh)                 dQ[0] = sum_k dS[k] K[k] / sqrt(dh),   dQ[q > 0] = 0
 // -- rank-one outputs, no matrix product.  The general kernels load four LDS images and run two MFMA passes for this
 // (177 us per ViT-B/16 layer at B = 256, plus a 232 MB memset of dqkv in the caller); here one workgroup per (batch, head)
-// streams K and V once, thread k owning key k (a whole 64- or 128-byte row per thread: full-line loads and stores), in
-// fp32.  HBM-bound: reads K, V (155 MB) + writes dqkv (232 MB, the zero rows of dQ included, so no memset).
+// streams K and V once (8 or 4 lanes per key row, so that every wave instruction moves whole lines), in fp32.  HBM-bound: reads K, V (155 MB) + writes dqkv (232 MB, the zero rows of dQ included, so no memset).
 #include "sc_attn_common.h"
 
 namespace {
@@ -16,9 +15,13 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16* __restric
                                                            const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, bf16* __restrict__ dqkv, int L, int H,
                                                            float scale, int causal) {
-    __shared__ float q0[DH], g0[DH], red[4][DH], sds[MAXL], sdel;
-    constexpr int CH = DH / 8;                           // 16-byte chunks per row
+    // CH lanes share a row (16 bytes each): one wave instruction covers 64 / CH whole rows, i.e. full 128- / 64-byte lines
+    // (a lane-per-row layout made every 16-byte load touch 64 different lines: 195 us instead of ~80 at B = 256)
+    constexpr int CH = DH / 8;                           // 16-byte chunks per row: 8 (dh 64) or 4 (dh 32)
+    constexpr int RPW = 64 / CH;                         // rows per wave instruction
+    __shared__ float q0[DH], g0[DH], red[4][DH], sdel;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int c = lane % CH, r = lane / CH;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int d = H * DH;
     const long long rs = 3LL * d;
@@ -42,58 +45,58 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16* __restric
     const float dl = sdel;
     const float nl2 = -lse[((long long)b * H + h) * L] * 1.4426950408889634f;
     const float c2 = scale * 1.4426950408889634f;
-    for (int k = t; k < L; k += 256) {
-        const bf16* krow = base + (long long)k * rs + d;
-        const bf16* vrow = krow + d;
-        float s = 0.f, dp = 0.f;
-        bf16x8 kk[CH], vv[CH];
+    float qc[8], gc[8], dq[8];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            kk[c] = *reinterpret_cast<const bf16x8*>(krow + c * 8);
-            vv[c] = *reinterpret_cast<const bf16x8*>(vrow + c * 8);
+    for (int e = 0; e < 8; ++e) { qc[e] = q0[c * 8 + e]; gc[e] = g0[c * 8 + e]; dq[e] = 0.f; }
+    const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
+    for (int k0 = wave * RPW; k0 < L; k0 += 4 * RPW) {
+        const int k = k0 + r;
+        const bool live = k < L;
+        const int kc = live ? k : L - 1;
+        const bf16x8 kk = *reinterpret_cast<const bf16x8*>(base + (long long)kc * rs + d + c * 8);
+        const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + (long long)kc * rs + 2 * d + c * 8);
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s = fmaf(qc[e], (float)kk[e], s);
+            dp = fmaf(gc[e], (float)vv[e], dp);
         }
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                s = fmaf(q0[c * 8 + e], (float)kk[c][e], s);
-                dp = fmaf(g0[c * 8 + e], (float)vv[c][e], dp);
-            }
+        for (int o = 1; o < CH; o <<= 1) {               // over the CH lanes of the row
+            s += __shfl_xor(s, o, 64);
+            dp += __shfl_xor(dp, o, 64);
+        }
         float p = fast_exp2(fmaf(s, c2, nl2));
-        if (causal && k > 0) p = 0.f;                    // query 0 sees key 0 only
+        if ((causal && k > 0) || !live) p = 0.f;         // query 0 sees key 0 only
         const float ds = p * (dp - dl);
-        sds[k] = ds;
-        bf16* dkrow = dbase + (long long)k * rs + d;
-        bf16* dvrow = dkrow + d;
         const float dsk = ds * scale;
+        bf16x8 ok, ov;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            bf16x8 ok, ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ok[e] = (bf16)(dsk * q0[c * 8 + e]);
-                ov[e] = (bf16)(p * g0[c * 8 + e]);
-            }
-            *reinterpret_cast<bf16x8*>(dkrow + c * 8) = ok;
-            *reinterpret_cast<bf16x8*>(dvrow + c * 8) = ov;
+        for (int e = 0; e < 8; ++e) {
+            ok[e] = (bf16)(dsk * qc[e]);
+            ov[e] = (bf16)(p * gc[e]);
+            dq[e] = fmaf(ds, (float)kk[e], dq[e]);       // dQ[0] = sum_k dS[k] K[k] (x scale at the end)
+        }
+        if (live) {
+            *reinterpret_cast<bf16x8*>(dbase + (long long)k * rs + d + c * 8) = ok;
+            *reinterpret_cast<bf16x8*>(dbase + (long long)k * rs + 2 * d + c * 8) = ov;
+            if (k > 0) *reinterpret_cast<u32x4*>(dbase + (long long)k * rs + c * 8) = z;     // dQ of an unconsumed query
         }
     }
-    __syncthreads();
-    // dQ[0][e] = scale * sum_k dS[k] K[k][e]: wave w takes keys w, w+4, ...; lanes = columns (K rows come from L2 now)
-    {
-        float acc = 0.f;
-        if (lane < DH)
-            for (int k = wave; k < L; k += 4) acc = fmaf(sds[k], (float)base[(long long)k * rs + d + lane], acc);
-        if (lane < DH) red[wave][lane] = acc;
+    // dQ[0]: sum the per-lane partials over the rows of the wave (lanes with equal c), then over the four waves
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = dq[e];
+#pragma unroll
+        for (int o = CH; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        dq[e] = v;
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave][c * 8 + e] = dq[e];
     }
     __syncthreads();
     if (t < DH) dbase[t] = (bf16)((red[0][t] + red[1][t] + red[2][t] + red[3][t]) * scale);
-    // dQ of the queries nobody consumed: exact zeros (the qkv data-gradient GEMM reads every row of dqkv)
-    const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
-    for (int i = t; i < (L - 1) * CH; i += 256) {
-        const int row = 1 + i / CH, c = i % CH;
-        *reinterpret_cast<u32x4*>(dbase + (long long)row * rs + c * 8) = z;
-    }
 }
 
 }  // namespace

@@ -42,7 +42,9 @@ __global__ void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ 
     }
 }
 
-// one wave per token row
+// one wave per token row; NV = 16-byte lane slots per row (ceil(d / 256)): a compile-time trip count keeps every load of a
+// row in flight at once (the generic 8-slot loop with run-time predicates ran at 2.5 TB/s, the LayerNorm kernels at 5.7)
+template <int NV>
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ x,
@@ -55,10 +57,10 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const float* __restri
     const float* src = tkn == 0 ? cls : patch + ((long long)b * (L - 1) + (tkn - 1)) * d;
     const float* pr = pos + (long long)tkn * d;
     const int nv = d >> 2;
-    f32x4 v[MAXV];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
         if (e < nv) {
             v[i] = ld4(src + e * 4) + ld4(pr + e * 4);
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const float* __restri
     const float mu = sc_wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
         if (e < nv) {
 #pragma unroll
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const float* __restri
     const float rs = rsqrtf(sc_wave_sum(q) / (float)d + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
         if (e < nv) {
             const f32x4 g = ld4(gamma + e * 4), bb = ld4(beta + e * 4);
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const float* __restri
     }
 }
 
+template <int NV>
 __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(float* __restrict__ dres, const float* __restrict__ patch,
                                                            const float* __restrict__ cls, const float* __restrict__ pos,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -99,9 +102,9 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(float* __restrict__ d
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
     const int rows = B * L;
-    f32x4 ag[MAXV], ab[MAXV], gm[MAXV];
+    f32x4 ag[NV], ab[NV], gm[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         ag[i] = ab[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int e = i * 64 + lane;
         gm[i] = e < nv ? ld4(gamma + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -112,10 +115,10 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(float* __restrict__ d
         const float* pr = pos + (long long)tkn * d;
         const float mu = mean[row], rs = rstd[row];
         float* dr = dres + (long long)row * d;
-        f32x4 g[MAXV], xh[MAXV];
+        f32x4 g[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int e = i * 64 + lane;
             if (e < nv) {
                 const f32x4 dyv = ld4(dr + e * 4);
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(float* __restrict__ d
         s1 = sc_wave_sum(s1) / (float)d;
         s2 = sc_wave_sum(s2) / (float)d;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int e = i * 64 + lane;
             if (e < nv) {
                 f32x4 o;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(float* __restrict__ d
     }
     float* sm = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
         if (e < nv) {
             st4(sm + (wave * 2 + 0) * d + e * 4, ag[i]);
@@ -163,22 +166,48 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(float* __restrict__ d
     for (int e = threadIdx.x; e < 2 * d; e += 256) pout[e] = sm[e] + sm[2 * d + e] + sm[4 * d + e] + sm[6 * d + e];
 }
 
-__global__ void colvec2_finalize_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ o0,
-                                        float* __restrict__ o1) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * d) return;
+// out_k[c] = sum_b partial[b][k][c], k = 0, 1: block = 64 columns x 16 row groups, eight loads in flight per thread, fixed
+// summation order (deterministic)
+__global__ __launch_bounds__(1024) void colvec2_finalize_kernel(const float* __restrict__ partial, int nblk, int d,
+                                                                 float* __restrict__ o0, float* __restrict__ o1) {
+    __shared__ float sm[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * 2 * d + e];
-    if (e < d) o0[e] = s; else o1[e - d] = s;
+    if (e < 2 * d) {
+        float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = ty;
+        for (; b + 7 * 16 < nblk; b += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] += partial[(long long)(b + u * 16) * 2 * d + e];
+        }
+        for (int u = 0; b < nblk; b += 16, ++u) p[u & 7] += partial[(long long)b * 2 * d + e];
+        s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    }
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < 2 * d) {
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sm[k][tx];
+        if (e < d) o0[e] = s; else o1[e - d] = s;
+    }
 }
 
 // out[i] = sum_b x[b*n + i], i < n (n = L*d), float4 lanes
 __global__ void batch_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, long long n4) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b) s += reinterpret_cast<const f32x4*>(x)[(long long)b * n4 + i];
-    reinterpret_cast<f32x4*>(out)[i] = s;
+    f32x4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 3 < B; b += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] += reinterpret_cast<const f32x4*>(x)[(long long)(b + u) * n4 + i];
+    }
+    for (int u = 0; b < B; ++b, ++u) p[u & 3] += reinterpret_cast<const f32x4*>(x)[(long long)b * n4 + i];
+    reinterpret_cast<f32x4*>(out)[i] = (p[0] + p[1]) + (p[2] + p[3]);
 }
 
 }  // namespace
@@ -200,15 +229,25 @@ extern "C" int sc_embed_ln_fwd(const float* patch_out, const float* cls, const f
                                const float* beta, float* x, float* mean, float* rstd, int B, int L, int d, float eps,
                                void* stream) {
     SC_CHECK(B > 0 && L > 1 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_embed_ln_fwd: bad shape B=%d L=%d d=%d", B, L, d);
-    embed_ln_fwd_kernel<<<(B * L + 3) / 4, 256, 0, (hipStream_t)stream>>>(patch_out, cls, pos, gamma, beta, x, mean,
-                                                                        rstd, B, L, d, eps);
+#define SC_EMBED_FWD(NV) embed_ln_fwd_kernel<NV><<<(B * L + 3) / 4, 256, 0, (hipStream_t)stream>>>(patch_out, cls, pos, gamma, beta, x, mean, rstd, B, L, d, eps)
+    switch ((d / 4 + 63) / 64) {
+        case 1: SC_EMBED_FWD(1); break;
+        case 2: SC_EMBED_FWD(2); break;
+        case 3: SC_EMBED_FWD(3); break;
+        case 4: SC_EMBED_FWD(4); break;
+        case 5: SC_EMBED_FWD(5); break;
+        case 6: SC_EMBED_FWD(6); break;
+        case 7: SC_EMBED_FWD(7); break;
+        default: SC_EMBED_FWD(8); break;
+    }
+#undef SC_EMBED_FWD
     SC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" long long sc_embed_ln_bwd_ws_floats(int B, int L, int d) {
     int nblk = (B * L + 3) / 4;
-    if (nblk > 256) nblk = 256;
+    if (nblk > 1024) nblk = 1024;      // 4 workgroups of 4 row-waves per CU: one per CU left the HBM-bound row loop latency-bound
     return (long long)nblk * 2 * d;
 }
 
@@ -219,15 +258,29 @@ extern "C" int sc_embed_ln_bwd(float* dres, const float* patch_out, const float*
     SC_CHECK(B > 0 && L > 1 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_embed_ln_bwd: bad shape B=%d L=%d d=%d", B, L, d);
     hipStream_t st = (hipStream_t)stream;
     int nblk = (B * L + 3) / 4;
-    if (nblk > 256) nblk = 256;
+    if (nblk > 1024) nblk = 1024;      // 4 workgroups of 4 row-waves per CU: one per CU left the HBM-bound row loop latency-bound
     const size_t lds = (size_t)4 * 2 * d * sizeof(float);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    embed_ln_bwd_kernel<<<nblk, 256, lds, st>>>(dres, patch_out, cls, pos, mean, rstd, gamma, (bf16*)dpatch_bf16, ws, B,
-                                                L, d);
+#define SC_EMBED_BWD(NV)                                                                                              \
+    do {                                                                                                              \
+        if (lds > 48 * 1024)                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel<NV>),                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+        embed_ln_bwd_kernel<NV><<<nblk, 256, lds, st>>>(dres, patch_out, cls, pos, mean, rstd, gamma,                  \
+                                                        (bf16*)dpatch_bf16, ws, B, L, d);                             \
+    } while (0)
+    switch ((d / 4 + 63) / 64) {
+        case 1: SC_EMBED_BWD(1); break;
+        case 2: SC_EMBED_BWD(2); break;
+        case 3: SC_EMBED_BWD(3); break;
+        case 4: SC_EMBED_BWD(4); break;
+        case 5: SC_EMBED_BWD(5); break;
+        case 6: SC_EMBED_BWD(6); break;
+        case 7: SC_EMBED_BWD(7); break;
+        default: SC_EMBED_BWD(8); break;
+    }
+#undef SC_EMBED_BWD
     SC_LAUNCH_CHECK();
-    colvec2_finalize_kernel<<<(2 * d + 255) / 256, 256, 0, st>>>(ws, nblk, d, dgamma, dbeta);
+    colvec2_finalize_kernel<<<(2 * d + 63) / 64, 1024, 0, st>>>(ws, nblk, d, dgamma, dbeta);
     SC_LAUNCH_CHECK();
     const long long n4 = (long long)L * d / 4;
     batch_sum_kernel<<<(int)((n4 + 255) / 256), 256, 0, st>>>(dres, dpos, B, n4);
