@@ -249,7 +249,7 @@ def test_colsum_l2norm_casts():
     assert torch.equal(dt.cpu(), bf(w).t())
 
 
-@pytest.mark.parametrize("P,S,d", [(8, 32, 64), (16, 224, 192), (14, 224, 64)])
+@pytest.mark.parametrize("P,S,d", [(8, 32, 64), (16, 224, 192), (14, 224, 64), (16, 64, 768), (8, 32, 1024), (16, 48, 1280)])
 def test_im2col_embed(P, S, d):
     ops = _ops()
     B = 3
