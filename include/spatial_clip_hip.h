@@ -114,10 +114,12 @@ int sc_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* 
 int sc_cast_pad_bf16(const float* src, long long ld_src, void* dst, long long ld_dst, int rows, int cols,
                      int cols_pad, void* stream);
 int sc_cast_transpose_bf16(const float* src, void* dst, int rows, int cols, long long ld_dst, void* stream);
-/* All transposed copies in ONE launch: desc[n][5] (device int64) = {src offset in floats from `master`, dst pointer,
- * rows, cols, ld_dst}; tile_prefix[n+1] (device int32) = running count of 64x64 tiles. */
-int sc_cast_transpose_batched(const float* master, const long long* desc, const int* tile_prefix, int n,
-                              int total_tiles, void* stream);
+/* All transposed copies in ONE launch: desc[n][5] (device int64) = {src offset in elements from `master` / the
+ * mirror, dst pointer, rows, cols, ld_dst}; tile_prefix[n+1] (device int32) = running count of 64x64 tiles.  With
+ * mirror_bf16 != NULL (the flat bf16 mirror of the masters, same element offsets, e.g. just written by sc_adamw_step)
+ * the copies are made from it -- half the bytes read, bit-identical results; otherwise from the fp32 master. */
+int sc_cast_transpose_batched(const float* master, const void* mirror_bf16, const long long* desc,
+                              const int* tile_prefix, int n, int total_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ patch embedding
  * VisionTransformer._embeds (src/open_clip/transformer.py:783-798): conv1 with kernel = stride = patch is a GEMM

@@ -360,9 +360,10 @@ def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_scale, norm_
                                    _ptr(p_bf16), _stream()), "sc_adamw_step")
 
 
-def cast_transpose_batched(master, desc, tile_prefix, n, total_tiles):
-    check(_lib.lib().sc_cast_transpose_batched(master.data_ptr(), desc.data_ptr(), tile_prefix.data_ptr(), n,
-                                               total_tiles, _stream()), "sc_cast_transpose_batched")
+def cast_transpose_batched(master, desc, tile_prefix, n, total_tiles, mirror_bf16=None):
+    check(_lib.lib().sc_cast_transpose_batched(master.data_ptr(), _ptr(mirror_bf16), desc.data_ptr(),
+                                               tile_prefix.data_ptr(), n, total_tiles, _stream()),
+          "sc_cast_transpose_batched")
 
 
 # ------------------------------------------------------------------------------------------ text tower glue

@@ -289,7 +289,8 @@ class ParamStore:
         if getattr(self, "_tp_desc", None) is None:
             self._build_transpose_plan()
         if self._tp_n:
-            ops.cast_transpose_batched(self.master, self._tp_desc, self._tp_prefix, self._tp_n, self._tp_tiles)
+            ops.cast_transpose_batched(self.master, self._tp_desc, self._tp_prefix, self._tp_n, self._tp_tiles,
+                                       mirror_bf16=self.master_bf16)      # the mirror is fresh at this point
         if self.fp8:                                      # per-output-channel e4m3 copies straight from the fp32 masters
             for c in self.copies.values():
                 if c.w8 is not None:

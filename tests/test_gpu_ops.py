@@ -405,3 +405,32 @@ def test_gelu_bf16_matches_the_gemm_epilogue_bitwise():
     torch.testing.assert_close(h2.float().cpu(), ref, atol=2e-2, rtol=1e-2)
     with pytest.raises(Exception):
         ops.gelu_bf16(u[:, :7].contiguous(), h[:, :7].contiguous())          # element count not a multiple of 8
+
+
+def test_cast_transpose_batched_from_master_and_from_mirror():
+    """All transposed bf16 weight copies in one launch: from the fp32 master and from the bf16 mirror (16-byte accesses
+    on interior 64x64 tiles, element-wise on edge tiles) -- both equal bf16(master)^T exactly."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    shapes = [(128, 192), (100, 70), (512, 200), (64, 64), (72, 136)]
+    total = sum(r * c for r, c in shapes)
+    master = torch.randn(total, generator=g).cuda()
+    mirror = master.to(torch.bfloat16)
+    for use_mirror in (False, True):
+        outs, desc, prefix, off, tiles = [], [], [0], 0, 0
+        for r, c in shapes:
+            o = torch.full((c, r + 8), 5.0, dtype=torch.bfloat16, device="cuda")       # ld_dst = r + 8: padded rows
+            outs.append(o)
+            desc.append([off, o.data_ptr(), r, c, r + 8])
+            tiles += ((r + 63) // 64) * ((c + 63) // 64)
+            prefix.append(tiles)
+            off += r * c
+        d = torch.tensor(desc, dtype=torch.int64, device="cuda")
+        p = torch.tensor(prefix, dtype=torch.int32, device="cuda")
+        ops.cast_transpose_batched(master, d, p, len(shapes), tiles, mirror_bf16=mirror if use_mirror else None)
+        off = 0
+        for (r, c), o in zip(shapes, outs):
+            want = master[off:off + r * c].view(r, c).to(torch.bfloat16).t()
+            assert torch.equal(o[:, :r].cpu(), want.cpu()), (use_mirror, r, c)
+            assert bool((o[:, r:] == 5.0).all())
+            off += r * c
