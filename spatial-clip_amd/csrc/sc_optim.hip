@@ -13,11 +13,21 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     __shared__ double sm[4];
     double acc = 0.0;
     const long long n4 = n >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (long long)gridDim.x * blockDim.x) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double a4[4] = {0.0, 0.0, 0.0, 0.0};                 // four loads in flight per thread, four independent fp64 chains
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x)[i + u * stride];
+            a4[u] += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    for (; i < n4; i += stride) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
         acc += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
     }
+    acc += (a4[0] + a4[1]) + (a4[2] + a4[3]);
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (long long i = n4 << 2; i < n; ++i) acc += (double)x[i] * x[i];
 #pragma unroll
