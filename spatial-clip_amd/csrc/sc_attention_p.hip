@@ -218,11 +218,29 @@ __global__ __launch_bounds__(1024) void attn_fwd_p_kernel(const bf16* __restrict
         // ---- epilogue: lane holds O[q][dt*16 + 4 lg .. +3]; rows >= Lq fall outside the descriptor and are dropped
         const float inv = 1.0f / lsum;
         const bool ok = q < Lq;
-        const unsigned orow = (unsigned)((((long long)b * L + q) * d + h * DH) * 2);
+        // O rows leave through a 1-KiB wave-private LDS strip, eight query rows per pass, so that a store instruction writes
+        // whole 128-byte rows (the accumulator layout would touch 16 rows x 32 B per instruction: see the backward kernels)
+        char* ostrip = smem + 4 * IMG + nqt * QSLOT + 64 + wave * 1024;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const u32x2 v = sc_pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
-            __builtin_amdgcn_raw_buffer_store_b64(v, out_rsrc, ok ? orow + (dt * 16 + lg * 4) * 2 : 0xFFFFFFF0u, 0, 0);
+        for (int half = 0; half < 2; ++half) {
+            if ((li >> 3) == half) {
+                const int r8 = li & 7;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    *reinterpret_cast<u32x2*>(ostrip + r8 * 128 + (((dt * 2 + (lg >> 1)) ^ (r8 >> 1)) << 4) + (lg & 1) * 8) =
+                        sc_pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const int r8 = lane >> 3, ch = lane & 7;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ostrip + r8 * 128 + ((ch ^ (r8 >> 1)) << 4));
+                const int qr = wave * 16 + half * 8 + r8;
+                const unsigned off = qr < Lq ? (unsigned)((((long long)b * L + qr) * d + h * DH + ch * 8) * 2) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, off, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
         const float l = mx * scale + __builtin_amdgcn_logf(lsum) * 0.6931471805599453f;     // lsum >= 1: raw v_log_f32
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, l), lse_rsrc,
@@ -261,7 +279,7 @@ int sc_attn_fwd_persistent(const void* qkv, void* out, float* lse, int B, int L,
     const int nheads = B * H;
     if (nqt + NLOAD > 16) return 0;
     const int nwaves = nqt + NLOAD;                         // one compute wave per query tile + the loader waves
-    const size_t lds = (size_t)4 * NB * 32 * dh * 2 + (size_t)nqt * QSLOT + 16;
+    const size_t lds = (size_t)4 * NB * 32 * dh * 2 + (size_t)nqt * QSLOT + 64 + (size_t)nqt * 1024;   // images, Q slots, counter, O strips
     if (lds > 160 * 1024) return 0;
     static int ncu = 0;
     if (!ncu) {
