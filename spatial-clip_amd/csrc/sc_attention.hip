@@ -501,7 +501,8 @@ extern "C" int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L,
     if (attn_check("sc_attn_fwd", B, L, H, dh)) return -1;
     const int Lq = (q_rows > 0 && q_rows < L) ? q_rows : L;
     hipStream_t st = (hipStream_t)stream;
-    static const bool persist_on = !(getenv("SC_ATTN_PERSIST") && getenv("SC_ATTN_PERSIST")[0] == '0');
+    const char* pe = getenv("SC_ATTN_PERSIST");                  // read per call, like SC_ATTN_BWD1 / SC_ATTN_BWD2
+    const bool persist_on = !(pe && pe[0] == '0');
     if (persist_on && sc_attn_fwd_persistent(qkv, out, lse, B, L, Lq, H, dh, causal, st)) {
         SC_LAUNCH_CHECK();
         return 0;

@@ -26,11 +26,10 @@ struct Rccl {
     bool ok = false;
 };
 
-Rccl& rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+// Resolved once; C++11 guarantees that the initialisation of a function-local static runs exactly once even when
+// several threads call in at the same time (the header promises re-entrancy).
+Rccl load_rccl() {
+    Rccl r;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
     for (const char* n : names)
@@ -51,6 +50,11 @@ Rccl& rccl() {
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.ReduceScatter && r.AllReduce;
     if (!r.ok) sc_set_error("RCCL library lacks a collective entry point");
+    return r;
+}
+
+Rccl& rccl() {
+    static Rccl r = load_rccl();
     return r;
 }
 

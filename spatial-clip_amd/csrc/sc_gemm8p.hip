@@ -511,6 +511,23 @@ SC_DEVICE bf16x8 tr_cat(u32x2 lo, u32x2 hi) {
 struct FragTN {                 // one operand fragment set: [kk][f] as two 64-bit halves
     u32x2 lo, hi;
 };
+// The asm reads above are invisible to hipcc's waitcnt pass, so the wait is written by hand -- and it must NAME the
+// registers it retires ("+v"): a clobber-only `s_waitcnt` orders memory, not registers, and the compiler may copy or
+// consume an asm-loaded register in front of it (seen in the attention kernels).  Same pattern as
+// tr_wait / tr_wait_b in sc_gemm256.hip.
+SC_DEVICE void tn_wait4(FragTN (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo),
+                   "+v"(f[3].hi)
+                 :: "memory");
+}
+SC_DEVICE void tn_wait8(FragTN (&f)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo),
+                   "+v"(f[3].hi), "+v"(f[4].lo), "+v"(f[4].hi), "+v"(f[5].lo), "+v"(f[5].hi), "+v"(f[6].lo), "+v"(f[6].hi),
+                   "+v"(f[7].lo), "+v"(f[7].hi)
+                 :: "memory");
+}
 
 template <int NF>
 SC_DEVICE void tn_read(unsigned base, const unsigned (&off)[NF], FragTN (&f)[2 * NF]) {
@@ -555,7 +572,10 @@ SC_DEVICE void phase_tn(char* smem, unsigned lds0, const StagerTN& S, int t, con
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // every fragment register this phase's reads wrote is tied to the wait that retires it
+    if (PH == 1) { tn_wait4(b0); tn_wait8(a); }
+    if (PH == 2) tn_wait4(b1);
+    if (PH == 3) tn_wait8(a);
     __builtin_amdgcn_sched_barrier(0);
     constexpr int mi = PH >= 3 ? 1 : 0;
     constexpr int nj = (PH == 2 || PH == 3) ? 1 : 0;
@@ -945,15 +965,6 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     }
     const int nblocks = g.ntm * g.ntn * splitk;
     if (mode == SC_GEMM_TN) {
-        // SC_GEMM_TN4W=1 selects the 4-wave kernel (128x128 per wave, a third fewer transposed LDS reads; sc_gemm4w.hip).
-        // Measured: +15 % at 4096^3 (L2-resident operands), +5 % on a ViT-B/16 weight-gradient shape run in a loop, but
-        // equal (+-3 %) on the step's sequence of four shapes with cold operands and 0.35 ms per step SLOWER inside the
-        // training step -- the token-major operand stream from HBM / L2, not the LDS issue rate, bounds these shapes.
-        const char* e4 = getenv("SC_GEMM_TN4W");
-        if (e4 && e4[0] == '1') {
-            const int rc4 = sc_gemm4w_tn(g, nblocks, st);
-            if (rc4 != 0) return rc4;
-        }
         return launch_tn(g, nblocks, st);
     }
     // persistent walk of the tile list for the store-only bf16 epilogues once there is more than one round of tiles

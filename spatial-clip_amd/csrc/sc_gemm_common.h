@@ -176,5 +176,3 @@ int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs,
 int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
 // fp8 (e4m3) NT variant of the same kernel; g.K / lda / ldb in 2-byte units, g.a_scale / g.b_scale set
 int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st);
-// 4-wave TN kernel (128x128 per wave, software-pipelined transposed LDS reads; sc_gemm4w.hip): 1 = launched, 0 = not eligible
-int sc_gemm4w_tn(const GemmArgs& g, int nblocks, hipStream_t st);

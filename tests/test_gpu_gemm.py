@@ -135,9 +135,7 @@ def test_nt_residual_gelu_dgelu(M, N, K):
                                           (576, 192, 37, 1), (2304, 768, 197 * 8, 8), (512, 20032, 8, 1),
                                           (768, 768, 2048, 8), (2304, 768, 1024, 4), (768, 3072, 640, 1),
                                           (512, 20000, 256, 1), (776, 200, 128, 2)])
-@pytest.mark.parametrize("four_wave", ["0", "1"])
-def test_tn_wgrad(M, N, K, splitk, four_wave, monkeypatch):
-    monkeypatch.setenv("SC_GEMM_TN4W", four_wave)         # 1: the 4-wave 128x128-per-wave kernel; 0 (default): the 8-wave one
+def test_tn_wgrad(M, N, K, splitk):
     ops = _ops()
     g = torch.Generator().manual_seed(K)
     at, bt = _rand((K, M), g), _rand((K, N), g)
@@ -148,11 +146,8 @@ def test_tn_wgrad(M, N, K, splitk, four_wave, monkeypatch):
 
 
 @pytest.mark.parametrize("K,splitk", [(64, 1), (128, 1), (192, 1), (320, 1), (576, 1), (1024, 1), (64 * 13, 4), (64 * 9, 9)])
-@pytest.mark.parametrize("four_wave", ["0", "1"])
-def test_tn_phase_interleaved_ring_exact(K, splitk, four_wave, monkeypatch):
-    """TN twin of the ring test above (transposed LDS reads, fused bias-gradient column sums): exact on small integers,
-    for the 8-wave kernel and for the 4-wave software-pipelined kernel (SC_GEMM_TN4W; plain fp32 output only)."""
-    monkeypatch.setenv("SC_GEMM_TN4W", four_wave)
+def test_tn_phase_interleaved_ring_exact(K, splitk):
+    """TN twin of the ring test above (transposed LDS reads, fused bias-gradient column sums): exact on small integers."""
     ops = _ops()
     M, N = 256 * 2 + 40, 256 * 3 + 24
     g = torch.Generator().manual_seed(K + splitk)
@@ -182,10 +177,8 @@ def test_tn_asymmetric_exact():
 
 @pytest.mark.parametrize("M,N,K,splitk", [(768, 768, 2048, 8), (3072, 768, 1024, 4), (2304, 768, 197 * 8, 2),
                                           (512, 200, 256, 1), (768, 3072, 256, 1)])
-@pytest.mark.parametrize("four_wave", ["0", "1"])
-def test_wgrad_with_fused_bias_grad(M, N, K, splitk, four_wave, monkeypatch):
+def test_wgrad_with_fused_bias_grad(M, N, K, splitk):
     ops = _ops()
-    monkeypatch.setenv("SC_GEMM_TN4W", four_wave)
     g = torch.Generator().manual_seed(K + M)
     dy, x = _rand((K, M), g), _rand((K, N), g)
     dw = torch.full((M, N), 9.0, dtype=torch.float32, device="cuda")

@@ -54,7 +54,9 @@ def test_attention_fwd_bwd(B, L, H, dh, causal):
 
 
 @pytest.mark.parametrize("B,L,H,causal,q_rows", [(64, 197, 12, False, 0), (110, 77, 8, True, 0), (70, 197, 12, False, 1),
-                                                 (300, 33, 3, False, 0), (37, 224, 9, True, 0)])
+                                                 (300, 33, 3, False, 0), (37, 224, 9, True, 0), (301, 33, 1, True, 0),
+                                                 (130, 65, 3, True, 0), (90, 223, 3, False, 0), (280, 223, 1, True, 0),
+                                                 (257, 65, 1, False, 1)])
 def test_attention_fwd_persistent_walks_many_heads(B, L, H, causal, q_rows):
     """More heads than CUs: every persistent workgroup walks several heads through its LDS double buffer (the DMA of
     head i+1 lands while head i computes; counted vmcnt past the previous head's stores).  Run twice: the second launch
@@ -78,6 +80,28 @@ def test_attention_fwd_persistent_walks_many_heads(B, L, H, causal, q_rows):
     assert torch.equal(o[:, :nq], o2[:, :nq]) and torch.equal(lse.cpu()[:, :, :nq], lse2.cpu()[:, :, :nq])
     if nq < L:                                          # rows past q_rows are not written
         assert bool((o[:, nq:] == 7.0).all()) and bool((lse.cpu()[:, :, nq:] == 7.0).all())
+
+
+@pytest.mark.parametrize("B,L,H,causal,q_rows", [(70, 197, 12, False, 0), (301, 33, 1, True, 0), (130, 65, 3, True, 0),
+                                                 (90, 223, 3, False, 0), (70, 197, 12, False, 1)])
+def test_attention_fwd_persistent_vs_per_head_kernel(B, L, H, causal, q_rows, monkeypatch):
+    """SC_ATTN_PERSIST is read per call: the same inputs through the persistent LDS-DMA kernel and through the
+    one-workgroup-per-head kernel must agree to bf16 rounding of the output (different softmax schedule: two-pass vs
+    online) -- the comparison tools/attn_fuzz.py makes over random shapes, pinned here on ragged and causal ones."""
+    ops = _ops()
+    dh, d = 64, H * 64
+    g = torch.Generator().manual_seed(B * 3 + L)
+    qd = bf(torch.randn(B * L, 3 * d, generator=g)).cuda()
+    outs = []
+    for persist in ("1", "0"):
+        monkeypatch.setenv("SC_ATTN_PERSIST", persist)
+        out = torch.full((B * L, d), 7.0, dtype=torch.bfloat16, device="cuda")
+        lse = torch.full((B, H, L), 7.0, device="cuda")
+        ops.attn_fwd(qd, B, L, H, dh, causal, out=out, lse=lse, q_rows=q_rows)
+        outs.append((out.float().cpu().view(B, L, d), lse.cpu()))
+    nq = q_rows if q_rows else L
+    torch.testing.assert_close(outs[0][0][:, :nq], outs[1][0][:, :nq], atol=1.6e-2, rtol=1.6e-2)
+    torch.testing.assert_close(outs[0][1][:, :, :nq], outs[1][1][:, :, :nq], atol=1e-4, rtol=1e-5)
 
 
 @pytest.mark.parametrize("path", ["persistent", "single_pass", "per_head"])

@@ -9,13 +9,6 @@ run("NT 4096^3", ops.NT, ops.EPI_BF16, 4096, 4096, 4096)
 run("TN 4096^3 (bf16 out n/a -> f32)", ops.TN, ops.EPI_F32, 4096, 4096, 4096)
 run("NT 4096^3 f32 out", ops.NT, ops.EPI_F32, 4096, 4096, 4096)
 M = 256 * 197
-for four in ("0", "1"):
-    os.environ["SC_GEMM_TN4W"] = four
-    run(f"TN 4096^3 four_wave={four}", ops.TN, ops.EPI_F32, 4096, 4096, 4096)
-    run(f"c_proj wgrad splitk=7 four_wave={four}", ops.TN, ops.EPI_F32, 768, 3072, M, splitk=7)
-    run(f"out_proj wgrad splitk=28 four_wave={four}", ops.TN, ops.EPI_F32, 768, 768, M, splitk=28)
-    run(f"qkv wgrad splitk=9 four_wave={four}", ops.TN, ops.EPI_F32, 2304, 768, M, splitk=9)
-os.environ["SC_GEMM_TN4W"] = "0"
 for sk in (1, 2, 4, 7, 14, 28):
     run(f"c_proj wgrad splitk={sk}", ops.TN, ops.EPI_F32, 768, 3072, M, splitk=sk)
 for sk in (7, 14, 28, 32):
