@@ -163,6 +163,36 @@ def shutdown() -> None:
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------- logged scalars
+def _scalar_device() -> torch.device:
+    """Where a scalar collective's tensor must live: the GPU for nccl (RCCL), anything for gloo."""
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def all_reduce_mean_scalars(values: List[float]) -> List[float]:
+    """Mean over ranks of a few host scalars in ONE collective (``self.log(..., sync_dist=True)``,
+    src/models/spatial_clip_module.py:105,107: Lightning reduces logged values with mean over the group).  Every rank
+    must call it with the same number of values.  No-op without a group."""
+    if not is_dist() or not values:
+        return list(values)
+    _, W = world()
+    t = torch.tensor(values, dtype=torch.float64, device=_scalar_device())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) / W for v in t.cpu()]
+
+
+def broadcast_flag(flag: bool, src: int = 0) -> bool:
+    """Rank ``src``'s decision for everybody (early stopping: all ranks must leave the epoch loop together, or the ones
+    that stay block in the next collective)."""
+    if not is_dist():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_scalar_device())
+    dist.broadcast(t, src=src)
+    return bool(int(t.cpu()[0]))
+
+
 # ---------------------------------------------------------------------------------------------- packing
 def _pack(feat: torch.Tensor, ids_a: Optional[torch.Tensor], ids_b: Optional[torch.Tensor], out: torch.Tensor) -> None:
     """out[B, D (+4)] = feat | ids_a (int64 as 2 floats) | ids_b.  Device tensors take the HIP pack kernel."""

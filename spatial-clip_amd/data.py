@@ -69,8 +69,13 @@ class SyntheticSpatialDataModule:
             yield synthetic_batch(self.batch_size, self.image_size, self.n_genes, self.k_neighbors, offset + s, rank, W,
                                   self._rates)
 
+    def set_epoch(self, epoch: int) -> None:
+        """Trainer.fit calls this before every epoch: each epoch draws new synthetic batches (seed offset)."""
+        self._epoch = int(epoch)
+
     def train_dataloader(self):
-        return _Loader(lambda: self._loader(self.steps_per_epoch, 0), self.steps_per_epoch)
+        return _Loader(lambda: self._loader(self.steps_per_epoch, getattr(self, "_epoch", 0) * self.steps_per_epoch),
+                       self.steps_per_epoch)
 
     def val_dataloader(self):
         return _Loader(lambda: self._loader(self.val_steps, 10_000), self.val_steps)

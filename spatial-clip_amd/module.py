@@ -72,6 +72,7 @@ class SpatialClipLitModule(torch.nn.Module):
         self.trainer = None
         self._feature_gather = None
         self.logged: Dict[str, Any] = {}
+        self.synced = set()                    # names logged with sync_dist=True
         # spatial_clip_module.py:44 -- cache the kwarg names the loss accepts, once
         self._loss_fn_arg_names = set(inspect.signature(self.loss_fn.forward).parameters.keys())
 
@@ -79,8 +80,14 @@ class SpatialClipLitModule(torch.nn.Module):
     def device(self) -> torch.device:
         return self.net.device_
 
-    def log(self, name: str, value, **kw) -> None:
+    def log(self, name: str, value, sync_dist: bool = False, **kw) -> None:
+        """Collects into ``self.logged`` (device scalars, no host sync).  ``sync_dist=True`` (the reference sets it on
+        every loss it logs, spatial_clip_module.py:105,107,113,121) marks the name in ``self.synced``: the trainer
+        averages those values over the ranks when it turns them into host numbers (``comm.all_reduce_mean_scalars``,
+        one collective per record)."""
         self.logged[name] = value.detach() if isinstance(value, torch.Tensor) else value
+        if sync_dist:
+            self.synced.add(name)
 
     def log_dict(self, metrics, **kw) -> None:
         self.logged["__metrics__" + metrics.prefix] = metrics

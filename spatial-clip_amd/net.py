@@ -130,7 +130,7 @@ class SpatialClipNet(torch.nn.Module):
     def __init__(self, model_name: str, pretrained: Optional[str] = None, aug_cfg: Optional[Any] = None,
                  cache_dir: Optional[str] = None, n_genes: Optional[int] = None, gene_hidden: Optional[int] = None,
                  device: Optional[str] = None, seed: int = 0, model_cfg: Optional[ModelCfg] = None,
-                 tokenizer_vocab: Optional[str] = None, precision: str = "bf16"):
+                 tokenizer_vocab: Optional[str] = None, precision: str = "bf16", grad_checkpointing: bool = False):
         super().__init__()
         if aug_cfg is not None and not isinstance(aug_cfg, (dict, AugmentationCfg)) and not is_dataclass(aug_cfg) \
                 and not hasattr(aug_cfg, "items"):
@@ -143,10 +143,10 @@ class SpatialClipNet(torch.nn.Module):
         if self.cfg.gene is None and self.cfg.text is None:
             raise ValueError(f"{model_name}: the model config has neither a text tower nor a gene tower")
         self.model_name = model_name
-        if precision not in ("bf16", "bf16-mixed", "fp8"):
-            raise ValueError(f"precision {precision!r}: 'bf16' (the reference's bf16-mixed policy) or 'fp8' "
-                             "(e4m3 forward GEMMs of the transformer blocks, BASELINE configs[4])")
-        self.precision = "fp8" if precision == "fp8" else "bf16"
+        if precision not in ("bf16", "bf16-mixed", "fp8", "fp8-mixed"):
+            raise ValueError(f"precision {precision!r}: 'bf16' / 'bf16-mixed' (the reference's bf16-mixed policy) or "
+                             "'fp8' / 'fp8-mixed' (e4m3 GEMMs of the transformer blocks, BASELINE configs[4])")
+        self.precision = "fp8" if precision.startswith("fp8") else "bf16"
         self.store = ParamStore(self.cfg, self.device_, seed=seed, fp8=self.precision == "fp8")
         for name, p in self.store.params.items():
             p._sc_store = self.store
@@ -166,6 +166,8 @@ class SpatialClipNet(torch.nn.Module):
         self.feature_gather = None          # comm.FeatureGather, installed per step by the module when W > 1
         if pretrained:
             self._load_pretrained(pretrained)
+        if grad_checkpointing:              # config key model.net.grad_checkpointing (open_clip: --grad-checkpointing)
+            self.set_grad_checkpointing(True)
 
     # ------------------------------------------------------------------ reference-facing helpers
     def set_grad_checkpointing(self, enable: bool = True) -> None:

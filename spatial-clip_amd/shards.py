@@ -203,15 +203,37 @@ class ShardedSpatialDataModule:
             return torch.from_numpy(np.stack([rank_weighted_vector(s, self.gene_to_idx, n) for s in sentences]))
         return self.tokenizer(sentences)          # reference text tower: int64 [B, 77]
 
+    def set_epoch(self, epoch: int) -> None:
+        """Called by ``Trainer.fit`` before each epoch's iteration: reshuffles the bucket sampler and draws fresh crop /
+        colour-jitter parameters (the reference: ``DataLoader(shuffle=True)`` + per-sample random transforms,
+        src/data/spatial_datamodule.py:91-101).  Deterministic per (seed, epoch, rank)."""
+        self._epoch = int(epoch)
+
+    def _eval_index_batches(self, n: int, bs: int, rank: int, W: int) -> List[List[int]]:
+        """Evaluation splits are read sequentially, every sample exactly once (``shuffle=False``,
+        spatial_datamodule.py:103-108), the last partial batch kept.  With W ranks: what Lightning's DistributedSampler
+        does for ``shuffle=False`` -- the index list is padded by wrap-around to a multiple of W and rank r takes
+        elements r, r + W, ...: every rank gets the same number of batches of the same sizes, which the gathered loss
+        needs."""
+        order = list(range(n))
+        if W > 1:
+            total = ((n + W - 1) // W) * W
+            order = (order + order[:total - n])[rank::W] if total > n else order[rank::W]
+        return [order[i:i + bs] for i in range(0, len(order), bs)]
+
     def _batches(self, name: str, train: bool) -> Iterator[Dict[str, Any]]:
         st = self._sets[name]
         index: ShardIndex = st["index"]
         rank, W = comm.world()
-        bs = min(self.batch_size, max(1, len(index) // max(W, 1)))
-        sampler = SpatialBucketBatchSampler(index, bs, W, rank, self.centers_per_batch, self.max_neighbors_per_center,
-                                            drop_last=train, seed=self.seed)
-        sampler.set_epoch(getattr(self, "_epoch", 0))
-        rng = np.random.default_rng([self.seed, getattr(self, "_epoch", 0), rank, 0 if train else 1])
+        epoch = getattr(self, "_epoch", 0)
+        if train:
+            bs = min(self.batch_size, max(1, len(index) // max(W, 1)))
+            sampler = SpatialBucketBatchSampler(index, bs, W, rank, self.centers_per_batch, self.max_neighbors_per_center,
+                                                drop_last=True, seed=self.seed)
+            sampler.set_epoch(epoch)
+        else:
+            sampler = self._eval_index_batches(len(index), self.batch_size, rank, W)
+        rng = np.random.default_rng([self.seed, epoch, rank, 0 if train else 1])
         dev = torch.device("cuda", torch.cuda.current_device())
         for idx in sampler:
             pngs, sents = zip(*(index.read(i) for i in idx))
@@ -226,7 +248,12 @@ class ShardedSpatialDataModule:
     def _loader(self, name: str, train: bool):
         if name not in self._sets:
             raise ValueError(f"split {name!r} was not set up (splits = {list(self.splits)})")
-        n = max(1, len(self._sets[name]["index"]) // max(self.batch_size * comm.world()[1], 1))
+        rank, W = comm.world()
+        n_items = len(self._sets[name]["index"])
+        if train:
+            n = max(1, n_items // max(self.batch_size * W, 1))
+        else:
+            n = len(self._eval_index_batches(n_items, self.batch_size, rank, W))
         return _Loader(lambda: self._batches(name, train), n)
 
     def train_dataloader(self):

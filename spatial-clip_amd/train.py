@@ -26,6 +26,10 @@ def train(cfg) -> Tuple[Dict[str, Any], Dict[str, Any]]:
     if cfg.get("seed") is not None:
         torch.manual_seed(int(cfg.seed))                       # L.seed_everything (src/train.py:56-57)
     datamodule = hydra_lite.instantiate(cfg.data)
+    # precision is a Trainer key in the reference (configs/trainer/default.yaml:15); here the GEMM operand type shapes the
+    # net's weight copies, so an fp8 trainer precision is handed to the net before it is built
+    if str(tcfg.get("precision", "bf16-mixed")).startswith("fp8") and isinstance(cfg.get("model", {}).get("net"), dict):
+        cfg.model["net"].setdefault("precision", "fp8")
     model = hydra_lite.instantiate(cfg.model)
     model.hparams["optimized_metric"] = cfg.get("optimized_metric", "val/loss")
     datamodule.preprocess_fn = model.net.preprocess_train      # handshake, src/train.py:70-73

@@ -62,8 +62,12 @@ class Trainer:
                  deterministic: bool = False, strategy: str = "auto", num_nodes: int = 1, sync_batchnorm: bool = False,
                  default_root_dir: Optional[str] = None, enable_checkpointing: bool = False, callbacks=None, logger=None,
                  val_check_interval: Any = 1.0, **unused):
-        if precision not in ("bf16-mixed", "bf16", "32", "32-true", 32):
-            raise ValueError(f"precision {precision!r}: the HIP path computes bf16 GEMMs with fp32 accumulation")
+        if precision not in ("bf16-mixed", "bf16", "fp8-mixed", "fp8", "32", "32-true", 32):
+            raise ValueError(f"precision {precision!r}: 'bf16-mixed' (bf16 MFMA GEMMs, fp32 accumulation / residual stream "
+                             "/ master weights) or 'fp8-mixed' (e4m3 MFMA GEMMs in the transformer blocks on the same policy)")
+        # the GEMM operand type is a property of the net (its weight copies are laid out for it at construction):
+        # train.train copies trainer.precision into model.net.precision, and fit() refuses a net built for another one
+        self.precision = "fp8" if str(precision).startswith("fp8") else "bf16"
         if accelerator == "cpu":
             raise RuntimeError("accelerator=cpu: this build has no CPU path (the oracle under oracle/ is test-only)")
         if strategy not in ("auto", "ddp", "ddp_find_unused_parameters_false", "ddp_find_unused_parameters_true", None):
@@ -136,11 +140,18 @@ class Trainer:
             model.validation_step(_to_device(batch, model.device), i)
             vl.append(model.logged["val/loss"])
         if vl:
-            out["val/loss"] = float(torch.stack(vl).mean())
+            out["val/loss"] = self._synced(model, "val/loss", float(torch.stack(vl).mean()))
             out.update(model.val_metrics.compute())
             if model.zero_shot_metric and model.gene_bank_embeddings is not None:
                 out["val/zero_shot_pcc"] = model.zero_shot_metric.compute()
         return out
+
+    @staticmethod
+    def _synced(model, name: str, value: float) -> float:
+        """Mean over ranks of a value the module logged with ``sync_dist=True`` (rank-local mean otherwise)."""
+        if name in getattr(model, "synced", ()):
+            return comm.all_reduce_mean_scalars([value])[0]
+        return value
 
     def _limit(self, n: int, frac) -> int:
         if self.fast_dev_run:
@@ -156,6 +167,11 @@ class Trainer:
         epochs = 1 if self.fast_dev_run else (self.max_epochs or 1)
         self.estimated_stepping_batches = n_train * epochs if self.max_steps == -1 else self.max_steps
         model.trainer = self
+        net_prec = getattr(model.net, "precision", "bf16")
+        if net_prec != self.precision:
+            raise RuntimeError(f"trainer.precision asks for {self.precision} GEMMs but the net was built with "
+                               f"precision={net_prec!r}: set model.net.precision (spatial_clip_amd.train does it from "
+                               "trainer.precision)")
         cfg = model.configure_optimizers()
         opt = cfg["optimizer"]
         sched = cfg.get("lr_scheduler", {}).get("scheduler")
@@ -175,6 +191,8 @@ class Trainer:
         self.val_runs = 0
         for epoch in range(start_epoch, epochs):
             self.current_epoch = epoch
+            if hasattr(datamodule, "set_epoch"):         # fresh shuffle + augmentation draws, also after a resume
+                datamodule.set_epoch(epoch)
             model.train_metrics.reset()
             t0 = time.time()
             skip = self.global_step - epoch * n_train if epoch == start_epoch else 0     # mid-epoch resume
@@ -193,7 +211,8 @@ class Trainer:
                     sched.step()
                 self.global_step += 1
                 if self.global_step % self.log_every_n_steps == 0 or self.fast_dev_run:
-                    self.history.append({"step": self.global_step, "train/loss": float(loss.detach())})
+                    self.history.append({"step": self.global_step,
+                                         "train/loss": self._synced(model, "train/loss", float(loss.detach()))})
                 if val_every and (i + 1) % val_every == 0 and (i + 1) < n_train \
                         and (epoch + 1) % self.check_val_every_n_epoch == 0:
                     self.history.append({"step": self.global_step, "epoch": epoch, **self._validate(model, datamodule)})
@@ -215,7 +234,9 @@ class Trainer:
     # ------------------------------------------------------------------ checkpoints (reference state_dict names)
     def _early_stop(self, rec: Dict[str, Any]) -> bool:
         """lightning.pytorch.callbacks.EarlyStopping on the epoch's validation record: stop after `patience` validated
-        epochs without an improvement of more than min_delta (every rank sees the same all-reduced metrics)."""
+        epochs without an improvement of more than min_delta.  The monitored value is the same on every rank when it is
+        an all-reduced metric (R@k) or a loss logged with sync_dist=True; rank 0's decision is broadcast regardless, so
+        that a rank-local monitor can never leave part of the group blocked in the next collective."""
         es = self.early_stopping
         if es is None or es["monitor"] not in rec:
             return False
@@ -226,25 +247,32 @@ class Trainer:
             es["best"], es["wait"] = v, 0
         else:
             es["wait"] += 1
-        self.should_stop = es["wait"] >= es["patience"]
+        self.should_stop = comm.broadcast_flag(es["wait"] >= es["patience"], src=0)
         return self.should_stop
 
     def _checkpoint_epoch(self, model, opt, sched, rec: Dict[str, Any]) -> None:
+        """Best / last bookkeeping runs on EVERY rank (Lightning broadcasts ``best_model_path``: src/train.py:122-128
+        reads it back on all ranks for ``trainer.test(ckpt_path=...)``); only the file writes / removals are rank 0's.
+        The paths are deterministic and the score is rank 0's, broadcast, so every rank names the same file."""
         cb = self.checkpoint_callback
         if cb is None:
             return
+        last = os.path.join(cb.dirpath, "last.ckpt")
         if self.is_global_zero:
             os.makedirs(cb.dirpath, exist_ok=True)
-            last = os.path.join(cb.dirpath, "last.ckpt")
             self.save_checkpoint(last, model, opt, sched, self.global_step)
-            cb.last_model_path = last
-            score = rec.get(cb.monitor)
-            if isinstance(score, float) and cb.is_better(score):
-                best = os.path.join(cb.dirpath, f"epoch_{int(rec['epoch']):03d}.ckpt")
+        cb.last_model_path = last
+        score = rec.get(cb.monitor)
+        improved = isinstance(score, float) and cb.is_better(score)
+        improved = comm.broadcast_flag(improved, src=0)
+        if improved:
+            best = os.path.join(cb.dirpath, f"epoch_{int(rec['epoch']):03d}.ckpt")
+            if self.is_global_zero:
                 self.save_checkpoint(best, model, opt, sched, self.global_step)
                 if cb.best_model_path and cb.best_model_path != best and os.path.exists(cb.best_model_path):
                     os.remove(cb.best_model_path)
-                cb.best_model_path, cb.best_model_score = best, score
+            cb.best_model_path = best
+            cb.best_model_score = float(score) if isinstance(score, float) else cb.best_model_score
         if comm.is_dist():
             torch.distributed.barrier()
 
@@ -290,6 +318,7 @@ class Trainer:
                 break
             model.test_step(_to_device(batch, model.device), i)
             tl.append(model.logged["test/loss"])
-        out = {"test/loss": float(torch.stack(tl).mean()), **model.test_metrics.compute()} if tl else {}
+        out = {"test/loss": self._synced(model, "test/loss", float(torch.stack(tl).mean())),
+               **model.test_metrics.compute()} if tl else {}
         self.callback_metrics = {**self.callback_metrics, **{k: v for k, v in out.items() if isinstance(v, float)}}
         return [out]

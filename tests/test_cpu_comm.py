@@ -134,3 +134,63 @@ def test_feature_gather_matches_synchronous_gather(world):
         ret = mgr.dict()
         mp.spawn(_fg_worker, args=(world, 29621 + world, ret), nprocs=world, join=True)
         assert dict(ret) == {r: 3 for r in range(world)}
+
+
+# ---------------------------------------------------------------------------- logged scalars / callbacks at W = 2
+class _StubNet:
+    precision = "bf16"
+
+    def state_dict(self):
+        return {"w": torch.zeros(2)}
+
+
+class _StubModel:
+    net = _StubNet()
+    synced = {"val/loss"}
+
+
+def _scalar_worker(rank, world, port, tmp, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), SC_DIST_BACKEND="gloo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import comm
+    from spatial_clip_amd.trainer import Trainer
+    out = {"mean": comm.all_reduce_mean_scalars([1.0 + rank, 10.0 * (rank + 1)]),
+           "flag": [comm.broadcast_flag(rank == 0), comm.broadcast_flag(rank == 1)]}
+    tr = Trainer(devices=world, strategy="ddp", enable_checkpointing=True, default_root_dir=tmp,
+                 callbacks={"early_stopping": {"monitor": "val/loss", "mode": "min", "patience": 1}})
+    model = _StubModel()
+    # sync_dist: the rank-local validation losses 1.0 / 3.0 become the group mean 2.0 on both ranks
+    out["synced"] = tr._synced(model, "val/loss", 1.0 + 2.0 * rank)
+    out["unsynced"] = tr._synced(model, "val/other", 1.0 + 2.0 * rank)
+    # rank-local monitor values that DISAGREE (rank 1 keeps improving, rank 0 does not): rank 0's decision wins everywhere
+    stops = []
+    for epoch, v in enumerate([(1.0, 1.0), (2.0, 0.5), (3.0, 0.2)]):
+        stops.append(tr._early_stop({"epoch": epoch, "val/loss": v[rank]}))
+    out["stops"] = stops
+    # checkpoint bookkeeping runs on every rank; only rank 0 writes
+    for epoch, score in enumerate([0.1, 0.3, 0.2]):
+        tr._checkpoint_epoch(model, None, None, {"epoch": epoch, "val/R@1": score})
+    cb = tr.checkpoint_callback
+    out["best"], out["last"], out["score"] = cb.best_model_path, cb.last_model_path, cb.best_model_score
+    out["files"] = sorted(os.listdir(cb.dirpath))
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_sync_dist_early_stop_and_best_checkpoint_agree_on_every_rank(tmp_path):
+    world, port = 2, 29000 + (os.getpid() * 7 + 3) % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_scalar_worker, args=(world, port, str(tmp_path), ret), nprocs=world, join=True)
+        r0, r1 = ret[0], ret[1]
+    assert r0["mean"] == r1["mean"] == [1.5, 15.0]
+    assert r0["flag"] == r1["flag"] == [True, False]
+    assert r0["synced"] == r1["synced"] == 2.0 and (r0["unsynced"], r1["unsynced"]) == (1.0, 3.0)
+    assert r0["stops"] == r1["stops"] == [False, True, True]
+    assert r0["best"] == r1["best"] and r0["best"].endswith("epoch_001.ckpt") and r0["score"] == r1["score"] == 0.3
+    assert r0["last"] == r1["last"] and r0["last"].endswith("last.ckpt")
+    assert r0["files"] == ["epoch_001.ckpt", "last.ckpt"]

@@ -90,3 +90,21 @@ def test_eval_recipe_composes(monkeypatch):
     cfg = hydra_lite.compose("eval.yaml", ["experiment=smoke_shards", "ckpt_path=/tmp/x.ckpt"])
     assert cfg.task_name == "eval" and cfg.ckpt_path == "/tmp/x.ckpt"
     assert cfg.model.net.model_name == "ViT-Ti-16-gene" and cfg.data.batch_size == 8
+
+
+def test_configs4_experiment_carries_precision_and_recompute_keys(monkeypatch):
+    """BASELINE configs[4] on the Hydra surface: model, per-GPU batch, fp8 trainer precision, activation recomputation."""
+    monkeypatch.setenv("PROJECT_ROOT", "/tmp/proj")
+    cfg = H.compose("train.yaml", ["experiment=vitl14_genetr_fp8_8gpu"])
+    assert cfg.model.net.model_name == "ViT-L-14-genetr" and cfg.model.net.grad_checkpointing is True
+    assert cfg.trainer.precision == "fp8-mixed" and cfg.trainer.devices == 8 and cfg.trainer.strategy == "ddp"
+    assert cfg.data.batch_size == 1024 and cfg.data.k_neighbors == 8
+    assert cfg.model.loss_fn._target_.endswith("SpatialLoss")
+    one = H.compose("train.yaml", ["experiment=vitl14_genetr_b256", "trainer.precision=fp8-mixed"])
+    assert one.trainer.devices == 1 and one.data.batch_size == 256 and one.trainer.precision == "fp8-mixed"
+    from spatial_clip_amd import trainer
+    tr = H.instantiate(one.trainer)
+    assert isinstance(tr, trainer.Trainer) and tr.precision == "fp8"
+    assert H.instantiate(H.compose("train.yaml", ["experiment=vitl14_genetr_b256"]).trainer).precision == "bf16"
+    with pytest.raises(ValueError):
+        H.instantiate({"_target_": "lightning.pytorch.Trainer", "precision": "16-mixed"})

@@ -169,3 +169,48 @@ def test_augmentation_draws_follow_random_resized_crop_and_jitter():
     assert E[:, :4].tolist() == [[0, 0, 200, 224]] * 3 and E[:, 4:7].tolist() == [[1, 1, 1]] * 3
     v = shards.rank_weighted_vector("B A Z C", {"A": 0, "B": 1, "C": 2}, 3)
     assert np.allclose(v, [1 - 1 / 3, 1.0, 1 - 2 / 3])
+
+
+def test_epochs_reshuffle_and_eval_splits_are_sequential():
+    """Trainer.fit calls datamodule.set_epoch(epoch); epoch 0 and 1 must differ (index lists / synthetic
+    seeds) while staying deterministic per (seed, epoch, rank); evaluation splits are read in order, exactly once."""
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data
+    from spatial_clip_amd.shards import ShardedSpatialDataModule
+    dm = data.SyntheticSpatialDataModule(batch_size=4, image_size=8, n_genes=16, steps_per_epoch=2, val_steps=1, k_neighbors=2)
+    dm.preprocess_fn = dm.tokenizer = lambda x: x
+    dm.setup("fit")
+    first = [b["texts"].clone() for b in dm.train_dataloader()]
+    again = [b["texts"].clone() for b in dm.train_dataloader()]
+    dm.set_epoch(1)
+    second = [b["texts"].clone() for b in dm.train_dataloader()]
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+    assert not any(torch.equal(a, b) for a, b in zip(first, second))
+    val0 = [b["texts"].clone() for b in dm.val_dataloader()]
+    dm.set_epoch(0)
+    assert all(torch.equal(a, b) for a, b in zip(val0, [b["texts"] for b in dm.val_dataloader()]))
+
+    sh = ShardedSpatialDataModule.__new__(ShardedSpatialDataModule)
+    assert sh._eval_index_batches(10, 4, 0, 1) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]      # last partial batch kept
+    r0, r1 = sh._eval_index_batches(7, 2, 0, 2), sh._eval_index_batches(7, 2, 1, 2)
+    assert r0 == [[0, 2], [4, 6]] and r1 == [[1, 3], [5, 0]]            # padded by wrap-around: equal steps and sizes
+    assert sorted(set(sum(r0 + r1, []))) == list(range(7))
+
+
+def test_bucket_sampler_epochs_differ_but_are_deterministic():
+    from spatial_clip_amd.sampler import SpatialBucketBatchSampler, build_fast_indices
+
+    class DS:
+        pass
+    n = 64
+    ds = DS()
+    ds.tile_ids = np.arange(n) + 100
+    ds.sample_ids = np.array(["s%d" % (i // 32) for i in range(n)])
+    edges = {int(t): [int(ds.tile_ids[(i + 1) % n])] for i, t in enumerate(ds.tile_ids)}
+    ds.id2idx, ds.sample_to_indices, ds.nbr_index = build_fast_indices(ds.tile_ids, ds.sample_ids, edges, 1)
+    DS.__len__ = lambda self: n
+    s = SpatialBucketBatchSampler(ds, 8, 1, 0, 4, 1, drop_last=True, seed=7)
+    s.set_epoch(0); e0 = [list(b) for b in s]
+    s.set_epoch(0); e0b = [list(b) for b in s]
+    s.set_epoch(1); e1 = [list(b) for b in s]
+    assert e0 == e0b and e0 != e1
