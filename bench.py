@@ -123,9 +123,16 @@ def cpu_baseline(model_name: str, n_genes: int):
             "legs": legs}
 
 
-def loss_delta_vs_oracle(m, n, cfg, batch_cpu, loss_kind: str):
-    """Half of BASELINE's metric: |loss(HIP, bf16-mixed) - loss(fp32 oracle)| on the SAME batch and the SAME weights at
-    the benchmark's own size, outside the timed region (oracle forward only: ~10 s of host time at B = 256)."""
+# Stated loss tolerances against the fp32 oracle (DESIGN.md sections 2 and 4c): the north-star bound for the reference's
+# bf16-mixed policy, and this build's own, looser bound for e4m3 GEMM operands.  The line prints the bound that applies
+# to the dtype it ran in, and whether the measured delta is inside it.
+LOSS_TOLERANCE = {"bf16": 1e-3, "fp8": 1e-2}
+FEATURE_TOLERANCE = {"bf16": 5e-3, "fp8": 4e-2}
+
+
+def loss_delta_vs_oracle(m, n, cfg, batch_cpu, loss_kind: str, dtype: str = "bf16", point: str = ""):
+    """Half of BASELINE's metric: |loss(HIP) - loss(fp32 oracle)| on the SAME batch and the SAME weights at the
+    benchmark's own size, outside the timed region (oracle forward only: ~10 s of host time at B = 256)."""
     import torch
     from oracle import spatial_clip_oracle as O
     torch.set_num_threads(host_cpu_share())
@@ -145,7 +152,9 @@ def loss_delta_vs_oracle(m, n, cfg, batch_cpu, loss_kind: str):
             "loss_delta_vs_oracle": abs(hip_loss - float(ref)),
             "max_abs_feature_delta": max(float((f_i - f["image_features"]).abs().max()),
                                          float((f_t - f["text_features"]).abs().max())),
-            "batch": int(batch_cpu["images"].shape[0]), "tolerance": 1e-3}
+            "batch": int(batch_cpu["images"].shape[0]), "point": point, "tolerance": LOSS_TOLERANCE[dtype],
+            "feature_tolerance": FEATURE_TOLERANCE[dtype],
+            "within_tolerance": bool(abs(hip_loss - float(ref)) <= LOSS_TOLERANCE[dtype])}
 
 
 def pmc_traffic_nt():
@@ -163,15 +172,36 @@ def pmc_traffic_nt():
     return round(tot / n) if n else None
 
 
+def visible_gpu_count() -> int:
+    """GPUs the ranks will see, counted in a THROW-AWAY child process: this process must not touch HIP before it starts
+    the ranks (a parent that has initialised the GPU may not start or exec other GPU programs on this pool), and whether
+    ``torch.cuda.device_count()`` initialises the runtime depends on the build (without amdsmi it falls through to
+    hipGetDeviceCount).  -1 = could not tell (the ranks themselves then report a missing device)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=600)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return -1
+
+
 def spawn_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU)
-    BEFORE this process makes any GPU call, and return their exit code.  Rank 0 of the children prints the JSON line."""
+    BEFORE this process makes any GPU call, and return their exit code.  Rank 0 of the children prints the JSON line.
+    SC_BENCH_SHARE_GPU=1 (with SC_DIST_BACKEND=gloo: RCCL ranks cannot share a device) lets the ranks share the visible
+    GPUs round-robin -- the rehearsal of this launch path on a 1-GPU box (tests/test_gpu_ddp.py)."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()          # counts devices without initialising the GPU
-    if have < n:
+    have = visible_gpu_count()
+    share = os.environ.get("SC_BENCH_SHARE_GPU", "0") == "1"
+    if have < 0:
+        have = n                               # unknown: let the ranks find out
+    if have < n and not (share and have >= 1):
         print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    if have < n and os.environ.get("SC_DIST_BACKEND", "nccl") == "nccl":
+        print("bench.py: SC_BENCH_SHARE_GPU=1 needs SC_DIST_BACKEND=gloo (two RCCL ranks cannot share one GPU)", file=sys.stderr)
         return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -274,6 +304,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Parity half of the metric, at the INITIAL weights (the meaningful point: nothing is memorised yet) ...
+    delta_init = None
+    if rank == 0 and world == 1 and not args.no_loss_delta:
+        note("loss delta vs the fp32 oracle at the initial weights (oracle forward on the host)")
+        delta_init = loss_delta_vs_oracle(m, n, cfg, data.synthetic_batch(B, cfg.vision.image_size, args.n_genes, 8, 0, 0, 1, rates),
+                                          args.loss, args.dtype, "initial weights, benchmark batch 0")
+        note(f"init-point loss delta {delta_init['loss_delta_vs_oracle']:.2e}, max feature delta "
+             f"{delta_init['max_abs_feature_delta']:.2e} (bound {delta_init['tolerance']:g})")
     note(f"model + {len(batches)} batches resident; warm-up ({args.warmup} steps)")
     for i in range(args.warmup):
         step(i)
@@ -316,7 +354,7 @@ def main():
         note(f"instrumented pass (single stream) done: {dt_inst / args.steps * 1e3:.2f} ms/step")
         events_ov, dt_ov = instrumented(True)
         note(f"instrumented pass (side stream on) done: {dt_ov / args.steps * 1e3:.2f} ms/step")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if world == 1 or dist.get_backend() == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
@@ -376,8 +414,11 @@ def main():
     delta = None
     if rank == 0 and world == 1 and not args.no_loss_delta:
         note("loss delta vs the fp32 oracle on one benchmark batch (oracle forward on the host)")
+        # ... and again on the weights the timed steps left behind (the two resident batches have been seen ~K/2 times
+        # each by then: an easier point to agree on; kept so that the trained-weights path is exercised too)
         delta = loss_delta_vs_oracle(m, n, cfg, data.synthetic_batch(B, cfg.vision.image_size, args.n_genes, 8, 0, 0, 1,
-                                                                     rates), args.loss)
+                                                                     rates), args.loss, args.dtype,
+                                     "weights after the warm-up + timed + instrumented steps, benchmark batch 0")
         note(f"loss delta {delta['loss_delta_vs_oracle']:.2e}, max feature delta {delta['max_abs_feature_delta']:.2e}")
     if rank == 0:
         cpu = None
@@ -401,9 +442,11 @@ def main():
                           "parallelism": f"dp{world}", "loss": float(loss.detach())},
                "n_gpus_live": dist.get_world_size() if world > 1 else 1,
                "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-               "loss_delta_vs_oracle": None if delta is None else delta["loss_delta_vs_oracle"],
-               "max_abs_feature_delta": None if delta is None else delta["max_abs_feature_delta"],
-               "parity": delta, "roofline": roofline, "cpu_baseline": cpu}
+               "loss_delta_vs_oracle": None if delta_init is None else delta_init["loss_delta_vs_oracle"],
+               "max_abs_feature_delta": None if delta_init is None else delta_init["max_abs_feature_delta"],
+               "loss_tolerance": LOSS_TOLERANCE[args.dtype],
+               "parity": None if delta_init is None else {"initial_weights": delta_init, "after_training_steps": delta},
+               "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     comm.shutdown()
 

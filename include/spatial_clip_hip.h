@@ -206,8 +206,11 @@ int sc_exp_scalar_bwd(const float* y, const float* dy, float* dx, float mult, vo
  * index; nbr_index[N][K] holds slide-local indices (-1 = fewer than K other tiles), alpha[N][K] the loss weights,
  * normalised per row: mode 0 weight = 1 / (distance + 1e-6) (docs/spatial_clip_data_pipeline.html, Step 1), mode 1
  * weight = exp(-d^2 / (2 sigma^2)) (notebooks/d1_dataset_construct_cw.ipynb).
- * sc_augment_tiles: decoded uint8 tiles [B][H][W][3] -> fp32 [B][3][S][S]: crop box + optional flip, bilinear resize,
- * ColorJitter (brightness / contrast / saturation factors applied in the per-sample order code 0..5), Normalize.
+ * sc_augment_tiles: decoded uint8 tiles [B][H][W][3] -> fp32 [B][3][S][S]: integer crop box, PIL's antialiased BICUBIC
+ * resize (two 8-bit passes, 22-bit fixed-point coefficients: what torchvision's resized_crop does to a PIL tile,
+ * src/open_clip/transform.py:153-154,186-204 with use_timm), optional horizontal flip, ColorJitter with PIL's 8-bit
+ * ImageEnhance semantics (brightness / contrast / saturation factors applied in the per-sample order code 0..5),
+ * ToTensor, Normalize: byte-identical to the PIL pipeline before ToTensor.
  * params12[B][12] = {x0, y0, crop_w, crop_h, brightness, contrast, saturation, order, flip, 0, 0, 0}; mean3 / std3 are
  * HOST pointers (configs/model/spatial_clip.yaml:12-17, src/open_clip/constants.py:1-2). */
 int sc_knn_alpha(const float* xy, int N, int K, int mode, float sigma, int* nbr_index, float* alpha, void* stream);

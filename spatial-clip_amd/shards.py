@@ -8,7 +8,8 @@ What runs where
   host    tar indexing, PNG inflate (PIL), string handling (gene sentence -> tokens through ``tokenizer``, or ->
           a rank-weighted gene vector for the gene towers), the random draws of the augmentation parameters
   device  K-nearest-neighbour search per slide and the loss weights alpha (``sc_knn_alpha``), RandomResizedCrop +
-          bilinear resize + ColorJitter + Normalize of the whole batch in one launch (``sc_augment_tiles``)
+          PIL-exact antialiased bicubic resize + flip + 8-bit ColorJitter + Normalize of the whole batch in one launch
+          (``sc_augment_tiles``; byte-identical to the PIL pipeline the reference runs, tests/golden/augment_pil.npz)
 The batch dict is the reference's ``_collate_fn`` contract (src/data/spatial_datamodule.py:110-137): ``images``,
 ``texts``, ``image_tile_ids`` = ``text_tile_ids``, ``neighbor_tile_ids`` (pad -1), ``neighbor_alphas`` (pad 0), ``raw_text``.
 Tile ids are global int64 row indices over (sorted slide ids, member order) like the reference's
@@ -131,6 +132,9 @@ def draw_aug_params(B: int, H: int, W: int, aug_cfg: Optional[Dict[str, Any]], r
     ratio = tuple(aug_cfg.get("ratio", (0.75, 1.3333)))
     j = aug_cfg.get("color_jitter", 0.0) or 0.0
     j = float(j[0]) if isinstance(j, (list, tuple)) else float(j)
+    # timm's create_transform flips with its default hflip = 0.5 (the reference passes no hflip, transform.py:186-204);
+    # the torchvision fallback branch (use_timm false) has no flip
+    flip_p = float(aug_cfg.get("hflip", 0.5 if aug_cfg.get("use_timm") else 0.0))
     for b in range(B):
         cw, ch, x0, y0 = W, H, 0.0, 0.0
         for _ in range(10):
@@ -144,6 +148,8 @@ def draw_aug_params(B: int, H: int, W: int, aug_cfg: Optional[Dict[str, Any]], r
         else:
             x0, y0 = (W - cw) / 2, (H - ch) / 2
         P[b, 0:4] = (x0, y0, cw, ch)
+        if flip_p > 0:
+            P[b, 8] = float(rng.uniform() < flip_p)
         if j > 0:
             P[b, 4:7] = rng.uniform(max(0.0, 1 - j), 1 + j, size=3)
             P[b, 7] = float(rng.integers(0, 6))

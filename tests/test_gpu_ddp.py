@@ -263,3 +263,27 @@ def test_bench_under_torchrun_two_ranks_prints_one_line():
     assert out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak" and out["value"] > 0
     r = subprocess.run(base + ["--gpus", "4"] + args, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (WORLD_SIZE unset): bench.spawn_ranks counts the devices in a
+    throw-away child, starts torch.distributed.run itself before touching the GPU and returns the ranks' exit code.
+    The two ranks share this box's one GPU (explicit opt-in SC_BENCH_SHARE_GPU=1, gloo).  Without the opt-in the same
+    command refuses (exit 2) instead of oversubscribing the device."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SC_DIST_BACKEND="gloo", SC_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model",
+           "ViT-Ti-16-gene", "--batch", "16", "--n-genes", "512", "--no-cpu-baseline", "--no-loss-delta", "--no-kernel-events"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_gpus_live"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0
+    if torch.cuda.device_count() < 2:
+        env.pop("SC_BENCH_SHARE_GPU")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 2 and "GPU(s) are visible" in r.stderr

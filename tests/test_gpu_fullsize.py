@@ -139,3 +139,96 @@ def test_vitb16_b256_loss_within_1e3_of_fp32_oracle(which):
     assert out["logits"].shape == (B, B)                   # model_step's output contract (spatial_clip_module.py:66-70)
     torch.testing.assert_close(out["logits"].cpu(), (f["image_features"] @ f["text_features"].t()) * f["logit_scale"],
                                atol=14.3 * 5e-3 * 2, rtol=0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: ViT-L/14 image tower (24 layers, width 1024, patch 14, 257 tokens) + 6-layer gene transformer
+# (79 patches of 256 genes, width 512), at FULL depth and geometry.  Oracle forward at a batch the host can afford.
+def _vitl_genetr(precision, seed=0, lr=3e-4, recompute=False):
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import losses, module, net, optim
+    n = net.SpatialClipNet("ViT-L-14-genetr", None, n_genes=20000, seed=seed, precision=precision,
+                           grad_checkpointing=recompute)
+    loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                 neighbor_alpha_scale=0.5, float32_logits=True)
+    m = module.SpatialClipLitModule(
+        n, loss_fn, functools.partial(optim.FusedAdamW, lr=lr, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+
+    class T:
+        max_steps, max_epochs, estimated_stepping_batches = 100, None, 100
+    m.trainer = T()
+    return n, m
+
+
+# stated bounds against the fp32 oracle on identical weights and batch: the north-star's for the bf16-mixed policy, this
+# build's own for e4m3 GEMM operands (bench.py prints the same pair as LOSS_TOLERANCE / FEATURE_TOLERANCE)
+CFG4_BOUNDS = {"bf16": (1e-3, 5e-3), "fp8": (1e-2, 4e-2)}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_configs4_vitl14_gene_transformer_full_depth_vs_fp32_oracle(precision):
+    from oracle import spatial_clip_oracle as O
+    from spatial_clip_amd import data
+    B = 32
+    n, m = _vitl_genetr(precision, seed=3)
+    cfg = n.cfg
+    assert cfg.vision.layers == 24 and cfg.vision.width == 1024 and cfg.vision.patch_size == 14 and cfg.vision.tokens == 257
+    assert cfg.gene.kind == "transformer" and cfg.gene.layers == 6 and cfg.embed_dim == 768
+    batch = data.synthetic_batch(B, 224, 20000, K=8)
+    with torch.no_grad():
+        out = m.model_step({k: v.cuda() for k, v in batch.items()})
+        torch.cuda.synchronize()
+        v, g = cfg.vision, cfg.gene
+        ocfg = O.ModelCfg(cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
+                          O.GeneCfg(g.n_genes, g.hidden, g.kind, g.patch, g.width, g.layers, g.head_width, g.mlp_ratio))
+        p = {k: t.cpu() for k, t in n.state_dict().items()}
+        torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+        f = O.net_forward(batch["images"], batch["texts"], p, ocfg)
+        ref = O.spatial_loss(f["image_features"], f["text_features"], f["logit_scale"], batch["image_tile_ids"],
+                             batch["text_tile_ids"], batch["neighbor_tile_ids"], batch["neighbor_alphas"])
+    dl = abs(float(out["loss"]) - float(ref))
+    dfi = float((out["image_features"].cpu() - f["image_features"]).abs().max())
+    dft = float((out["text_features"].cpu() - f["text_features"]).abs().max())
+    tol_l, tol_f = CFG4_BOUNDS[precision]
+    print(f"[configs4 {precision}] loss {float(out['loss']):.6f} vs oracle {float(ref):.6f}: |d|={dl:.2e} (bound {tol_l:g}); "
+          f"max|d feature| image {dfi:.2e} gene {dft:.2e} (bound {tol_f:g})")
+    assert dl <= tol_l and dfi <= tol_f and dft <= tol_f
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_configs4_per_gpu_batch_1024_with_recomputation_properties(precision):
+    """configs[4] at its stated 1024 pairs per GPU (global batch 8192 on 8 GPUs) needs activation recomputation to fit
+    288 GB.  The oracle cannot run this size; properties instead: finite loss / gradients, two steps from the same seed
+    bit-identical (no float atomics anywhere on the path), the loss on a fixed batch goes down, peak HBM below the
+    device's capacity and near DESIGN's estimate."""
+    from spatial_clip_amd import data
+    B = 1024
+    free, total = torch.cuda.mem_get_info()
+    if total < 250 * 2 ** 30:
+        pytest.skip("needs the 288 GB of an MI355X")
+    batch = {k: v.cuda() for k, v in data.synthetic_batch(B, 224, 20000, K=8).items()}
+    runs = []
+    for rep in range(2):
+        torch.cuda.reset_peak_memory_stats()
+        n, m = _vitl_genetr(precision, seed=5, recompute=True)
+        oc = m.configure_optimizers()
+        opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+        ls, gn = [], []
+        for step in range(3 if rep == 0 else 2):
+            loss = m.training_step(batch, step)
+            loss.backward()
+            nc = opt.step(grad_scale=1.0, max_norm=1.0)
+            sched.step()
+            ls.append(float(loss.detach()))
+            gn.append(float(nc[0]))
+        torch.cuda.synchronize()
+        runs.append((ls, gn, n.store.p("visual.proj").clone(), torch.cuda.max_memory_allocated() / 2 ** 30))
+        del n, m, opt, sched, oc, loss
+        torch.cuda.empty_cache()
+    (l0, g0, w0, peak), (l1, g1, w1, _) = runs
+    print(f"[configs4 {precision} B=1024 recompute] losses {l0}, grad norms {g0}, peak HBM {peak:.1f} GiB")
+    assert all(x == x and abs(x) < 1e4 for x in l0 + g0)
+    assert l0[:2] == l1 and g0[:2] == g1                      # bit-reproducible
+    assert l0[2] < l0[1]                                      # step 0 runs at lr = 0 (LambdaLR warm-up): compare from step 1
+    assert 120.0 < peak < 230.0, peak                          # DESIGN 4c': ~177 GiB with recomputation (233 GB without)

@@ -9,6 +9,8 @@ import torch
 
 from oracle import spatial_clip_oracle as O
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 torch.set_num_threads(4)
 
 
@@ -210,3 +212,26 @@ def test_aten_kernel_mode_matches_plain_mode():
         assert abs(float(a["grad_norm"]) - float(b["grad_norm"])) < 1e-5 * max(1.0, float(a["grad_norm"]))
     for k in pa:
         assert float((pa[k] - pb[k]).abs().max()) < 2e-5, k
+
+
+def test_augment_oracle_equals_pil_fixture_bitwise():
+    """oracle/augment_oracle.py (integer restatement of Pillow's resize / blend / luma as the reference's train transform
+    uses them) against outputs PIL itself produced (tests/golden/make_golden_augment.py): byte-identical, including the
+    float32 ToTensor / Normalize tail.  When PIL is importable the fixture is also regenerated and must not have moved."""
+    import numpy as np
+    from oracle import augment_oracle as A
+    z = np.load(os.path.join(GOLDEN, "augment_pil.npz"))
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    for name in ("up", "down", "same"):
+        src, P, want, S = z[name + "_src"], z[name + "_params"], z[name + "_out"], int(z[name + "_S"])
+        for b in range(src.shape[0]):
+            got = A.to_tensor_normalize(A.augment_u8(src[b], P[b], S), mean, std)
+            assert np.array_equal(got, want[b]), (name, b)
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mk_aug", os.path.join(GOLDEN, "make_golden_augment.py"))
+        mk = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mk)
+    except ImportError:
+        return
+    assert np.array_equal(mk.pil_pipeline(z["down_src"][3], z["down_params"][3], int(z["down_S"])), z["down_out"][3])
