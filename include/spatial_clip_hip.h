@@ -80,7 +80,9 @@ int sc_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * LayerNorm over the last dim of the fp32 residual stream (eps 1e-5; src/open_clip/transformer.py:23-29),
  * bf16 output feeding the next GEMM; mean/rstd [rows] saved for backward (may be NULL).
- * Backward: dres = (accumulate ? dres : 0) + LN'(dy); also writes the bf16 copy of the new dres (may be NULL),
+ * Backward: dres = (accumulate ? dres : 0) + LN'(dy) -- accumulate = 1: every row of dres carries an incoming residual
+ * gradient; accumulate = -P: only the rows r with r % P == 0 do (class-token rows behind a class-token-only block), the
+ * others are neither read nor pre-zeroed; also writes the bf16 copy of the new dres (may be NULL),
  * dgamma, dbeta and colsum = column sums of the new dres (= bias gradient of the Linear that produced the
  * residual branch; may be NULL).  ws: sc_layernorm_bwd_ws_floats() floats.  d % 4 == 0, d <= 2048.
  * dgamma == NULL defers the column reductions: the per-block partial sums stay in ws and

@@ -32,30 +32,37 @@ struct GemmArgs {
     float* colsum;        // TN + EPI_F32 only: [splitk][M] partial column sums of the At operand (bias gradient), or null
     const float* a_scale = nullptr;   // fp8 kernels only: per-row dequantisation factors of A [M] and B [N]
     const float* b_scale = nullptr;
+    int diag = 0;         // SC_EPI_DIAG (benchmark diagnostics only): 1 = GELU pair without its second store, 2 = without the GELU arithmetic
 };
 
 constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes and reads)
 
-// exact-erf GELU to 1.5e-7 (Abramowitz-Stegun 7.1.26) sharing one exp between erf and the Gaussian pdf:
-//   e = exp(-x^2/2);  erf(|x|/sqrt2) = 1 - poly(t) * e,  t = 1/(1 + p |x|/sqrt2)
-SC_DEVICE void sc_gelu_parts(float x, float& cdf, float& pdf) {
-    const float ax = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-    const float e = __expf(-ax * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * e;
-    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
-    pdf = 0.3989422804014327f * e;
+// exact-erf GELU to 1.5e-7 (Abramowitz-Stegun 7.1.26) sharing one exp between erf and the Gaussian pdf, arranged for the
+// fewest VALU issue slots (the GELU epilogues are VALU-bound while the matrix pipe idles: tools/bench_epi_diag.py):
+//   y = |x| sqrt(log2(e) / 2);  e = 2^(-y^2) = exp(-x^2 / 2);  t = 1 / (1 + p' y);  q(t) = poly(t) / 2
+//   erf(|x| / sqrt 2) = 1 - 2 q e   =>   gelu(x) = x Phi(x) = max(x, 0) - |x| q e
+//                                        gelu'(x) = Phi(x) + x phi(x) = [x >= 0] + e (x / sqrt(2 pi) - copysign(q, x))
+// 11 (gelu) / 14 (gelu') plain VALU operations + v_rcp + v_exp per element; abs / neg ride on source modifiers.
+SC_DEVICE void sc_gelu_qe(float x, float& q, float& e) {
+    const float y = fabsf(x) * 0.84932180028801904f;                       // sqrt(log2(e) / 2)
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.2727374808792225f, y, 1.0f));   // 0.3275911 / sqrt(log2 e)
+    e = __builtin_amdgcn_exp2f(-(y * y));
+    float r = __builtin_fmaf(t, 0.5307027145f, -0.7265760135f);            // poly / 2, Horner from the top
+    r = __builtin_fmaf(r, t, 0.7107068705f);
+    r = __builtin_fmaf(r, t, -0.142248368f);
+    r = __builtin_fmaf(r, t, 0.127414796f);
+    q = r * t;
 }
 SC_DEVICE float sc_gelu_fast(float x) {
-    float c, p;
-    sc_gelu_parts(x, c, p);
-    return x * c;
+    float q, e;
+    sc_gelu_qe(x, q, e);
+    return __builtin_fmaf(-fabsf(x), q * e, fmaxf(x, 0.0f));
 }
 SC_DEVICE float sc_gelu_grad_fast(float x) {
-    float c, p;
-    sc_gelu_parts(x, c, p);
-    return c + x * p;
+    float q, e;
+    sc_gelu_qe(x, q, e);
+    const float step = x >= 0.0f ? 1.0f : 0.0f;
+    return __builtin_fmaf(e, __builtin_fmaf(x, 0.3989422804014327f, -copysignf(q, x)), step);
 }
 
 // Stage one MFMA accumulator block (swapped orientation: lane owns C[m = li][n = 4*lg .. +3]) into the wave's LDS tile

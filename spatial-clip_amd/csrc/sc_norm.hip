@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
-// dres_new = (accumulate ? dres : 0) + LNbwd(dy); also emits the bf16 copy of dres_new (the A operand of
+// dres_new = (accumulate ? dres : 0) + LNbwd(dy) (accumulate = -P: dres only holds rows r % P == 0); also emits the bf16 copy of dres_new (the A operand of
 // the next dgrad / wgrad GEMMs) and per-block partials of dgamma, dbeta and colsum(dres_new).
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long long lddy,
@@ -118,11 +118,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         s2 = sc_wave_sum(s2) / (float)d;
         float* dr = dres + (long long)row * lddres;
         bf16* db = dres_bf ? dres_bf + (long long)row * lddbf : nullptr;
+        // accumulate > 0: every row of dres holds an incoming residual gradient; accumulate = -P: only rows r with
+        // r % P == 0 do (the class-token rows after a class-token-only block), the others start from zero and are not read
+        const bool acc_row = accumulate > 0 || (accumulate < 0 && (row % (-accumulate)) == 0);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int e = i * 64 + lane;
             if (e < nv) {
-                f32x4 o = accumulate ? ld4(dr + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 o = acc_row ? ld4(dr + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     o[c] += rs * (g[i][c] - s1 - xh[i][c] * s2);

@@ -158,8 +158,9 @@ def gelu_bf16(u: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, colsum, rows: int, d: int, *,
-                  accumulate: bool, lddy=None, ldx=None, lddres=None, lddbf=None, ws=None, defer_reduce: bool = False):
-    """``defer_reduce``: leave the per-block partial sums of dgamma / dbeta / colsum in ``ws`` (caller-owned, at least
+                  accumulate, lddy=None, ldx=None, lddres=None, lddbf=None, ws=None, defer_reduce: bool = False):
+    """``accumulate``: False / True, or a negative int -P: only rows r % P == 0 of ``dres`` carry an incoming gradient.
+    ``defer_reduce``: leave the per-block partial sums of dgamma / dbeta / colsum in ``ws`` (caller-owned, at least
     layernorm_bwd_ws_floats floats) and finish them with layernorm_bwd_reduce -- e.g. on the weight-gradient stream."""
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.float32, "x"); _req(dres, torch.float32, "dres")
     l = _lib.lib()

@@ -159,9 +159,10 @@ class TransformerStack:
                  bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
         return xo
 
-    def _backward_last_cls(self, dres_c: torch.Tensor, dres_c_bf: torch.Tensor, on_side) -> tuple:
-        """Backward of the CLS-only last block.  In: compact dL/d(x_out[CLS]) (fp32 + bf16).  Out: full fp32 / bf16
-        residual-gradient buffers holding dL/d(block input)."""
+    def _backward_last_cls(self, dres: torch.Tensor, dres_c_bf: torch.Tensor, on_side) -> tuple:
+        """Backward of the CLS-only last block.  In: dL/d(x_out[CLS]) in the class-token rows of the FULL fp32 buffer
+        ``dres`` [M, d] (the other rows hold nothing yet) + its compact bf16 copy.  Out: the same fp32 buffer and a full
+        bf16 buffer holding dL/d(block input) for every row."""
         s, d, H, dh, mlp, B, L, M = self.s, self.d, self.H, self.dh, self.mlp, self.B, self.L, self.M
         bf = self.bufs
         i = self.layers - 1
@@ -173,17 +174,18 @@ class TransformerStack:
             bf.get("c.xmid", (B, d), F32)
         dU = bf.get("c.dU", (B, mlp), BF16)
         dA_c = bf.get("c.dA", (B, d), BF16)
-        ops.gemm(ops.NT, ops.EPI_BF16_DGELU, dres_c_bf, cp("mlp.c_proj.weight").wb, dU, M=B, N=mlp, K=d, aux=u)
+        dres_c_bf_ = dres_c_bf
+        ops.gemm(ops.NT, ops.EPI_BF16_DGELU, dres_c_bf_, cp("mlp.c_proj.weight").wb, dU, M=B, N=mlp, K=d, aux=u)
 
         def w_mlp():
-            ops.gemm(ops.TN, ops.EPI_F32, dres_c_bf, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=B)
+            ops.gemm(ops.TN, ops.EPI_F32, dres_c_bf_, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=B)
             ops.gemm_wgrad_bias(dU, a2, g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), M=mlp, N=d, K=B)
         on_side(w_mlp, ())
         ops.gemm(ops.NT, ops.EPI_BF16, dU, cp("mlp.c_fc.weight").wb, dA_c, M=B, N=d, K=mlp)
         g1_c = bf.get("c.dres_bf1", (B, d), BF16)
         ops.layernorm_bwd(dA_c, xmid, bf.get("c.m2", (B,), F32), bf.get("c.r2", (B,), F32),
-                          s.p(self._n(i, "ln_2.weight")), dres_c, g1_c, g("ln_2.weight"), g("ln_2.bias"),
-                          g("attn.out_proj.bias"), B, d, accumulate=True)
+                          s.p(self._n(i, "ln_2.weight")), dres, g1_c, g("ln_2.weight"), g("ln_2.bias"),
+                          g("attn.out_proj.bias"), B, d, accumulate=True, lddres=L * d)      # in place on the class-token rows
         # attention branch: only the CLS rows of dO exist (written through a strided view); sc_attn_bwd with q_rows = 1
         # reads nothing else of dO / o and writes ALL of dqkv (zeros for the dq rows nobody consumed): no memsets
         dO = bf.get("dO", (M, d), BF16)
@@ -200,14 +202,11 @@ class TransformerStack:
         on_side(w_attn, (dqkv,))
         dA = bf.get("dA", (M, d), BF16)
         ops.gemm(ops.NT, ops.EPI_BF16, dqkv, cp("attn.in_proj_weight").wb, dA, M=M, N=d, K=3 * d)
-        dres = bf.get("dres_full", (M, d), F32)
-        dres.zero_()
-        dres.view(B, L * d)[:, :d].copy_(dres_c)                   # the residual path of the CLS rows
         dres_bf = bf.get("dres_bf.0", (M, d), BF16)
         prev_bias = s.g(self._n(i - 1, "mlp.c_proj.bias")) if i > 0 else None
         ops.layernorm_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
                           s.p(self._n(i, "ln_1.weight")), dres, dres_bf, g("ln_1.weight"), g("ln_1.bias"),
-                          prev_bias, M, d, accumulate=True)
+                          prev_bias, M, d, accumulate=-L)       # only the class-token rows carry a residual gradient
         return dres, dres_bf
 
     # -------------------------------------------------------------------------------- backward
@@ -423,7 +422,9 @@ class PatchTransformerTower:
         ops.gemm(ops.TN, ops.EPI_F32, pooled, d_raw, s.g(self._n("proj")), M=d, N=D, K=B)
         last = self.n_layers - 1
         if self.stack.cls_only_last:
-            dres = bf.get("dres_c", (B, d), F32)
+            # class-token-only last block: its fp32 residual gradient lives in the class-token rows of the FULL buffer
+            # (row stride L * d) from the start, so nothing has to be zeroed or copied when the full-width blocks take over
+            dres = self.stack.bufs.get("dres_full", (M, d), F32)
             dres_bf = bf.get("dres_c_bf", (B, d), BF16)
             ld = d
         else:
@@ -435,7 +436,7 @@ class PatchTransformerTower:
         ops.layernorm_bwd(d_pooled, self.xf, bf.get("m_post", (B,), F32), bf.get("r_post", (B,), F32),
                           s.p(self._n("ln_post.weight")), dres, dres_bf, s.g(self._n("ln_post.weight")),
                           s.g(self._n("ln_post.bias")), s.g(self._n(f"transformer.resblocks.{last}.mlp.c_proj.bias")),
-                          B, d, accumulate=False, ldx=self.x_ld, lddres=ld, lddbf=ld)
+                          B, d, accumulate=False, ldx=self.x_ld, lddres=L * d, lddbf=ld)
         if on_bucket is not None:
             on_bucket(self.param_names_head())
         cb = (lambda i: on_bucket(self.stack.layer_param_names(i))) if on_bucket is not None else None
