@@ -209,7 +209,7 @@ int sc_exp_scalar_bwd(const float* y, const float* dy, float* dx, float mult, vo
  * normalised per row: mode 0 weight = 1 / (distance + 1e-6) (docs/spatial_clip_data_pipeline.html, Step 1), mode 1
  * weight = exp(-d^2 / (2 sigma^2)) (notebooks/d1_dataset_construct_cw.ipynb).
  * sc_augment_tiles: decoded uint8 tiles [B][H][W][3] -> fp32 [B][3][S][S]: integer crop box, PIL's antialiased BICUBIC
- * resize (two 8-bit passes, 22-bit fixed-point coefficients: what torchvision's resized_crop does to a PIL tile,
+ * resize (two 8-bit passes, 22-bit fixed-point coefficients: what the reference's resized-crop transform does to a PIL tile,
  * src/open_clip/transform.py:153-154,186-204 with use_timm), optional horizontal flip, ColorJitter with PIL's 8-bit
  * ImageEnhance semantics (brightness / contrast / saturation factors applied in the per-sample order code 0..5),
  * ToTensor, Normalize: byte-identical to the PIL pipeline before ToTensor.
