@@ -55,12 +55,24 @@ int sc_gemm_wgrad_bias(const void* dY, int lddy, const void* X, int ldx, int M, 
  * quantised (sc_quantize_rows_fp8 writes 1/s per row; fixed_scale > 0 skips the amax pass), the products accumulate in
  * fp32 on the matrix cores (v_mfma_scale_f32_16x16x128_f8f6f4, block scale 1.0) and accumulator (m, n) is multiplied
  * by a_scale_inv[m] * b_scale_inv[n] before the bf16 kernel's epilogue (SC_EPI_BF16 / _BIAS / F32_BIAS_RES / GELU_PAIR /
- * F32).  NT only: C[M,N] = A8[M,K] . B8[N,K]^T, K % 128 == 0, lda / ldb in bytes (= elements), multiples of 16. */
+ * BF16_DGELU / F32).  NT only: C[M,N] = A8[M,K] . B8[N,K]^T, K % 128 == 0, lda / ldb in bytes (= elements), multiples of 16. */
 int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long ld_src, int rows, int cols, void* dst_fp8,
                          long long ld_dst, float* scale_inv, float fixed_scale, void* stream);
 int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
                 const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2, const float* bias,
-                const float* res, int ldres, void* stream);
+                const float* res, int ldres, const void* aux, int ldaux, void* stream);
+/* The quantiser fused into the kernels that hold a complete row (round 3): LayerNorm forward also emits the e4m3 copy
+ * of its output (A operand of the qkv / c_fc forward GEMMs), LayerNorm backward the e4m3 copy of the new residual
+ * gradient (A operand of the c_proj / out_proj data-gradient GEMMs; SC_EPI_BF16_DGELU takes aux = the pre-GELU tensor),
+ * each with its per-row 1/scale.  Same arguments as sc_layernorm_fwd / sc_layernorm_bwd plus the fp8 pointer, its row
+ * stride in bytes (multiple of 4) and scale_inv[rows]. */
+int sc_layernorm_fwd_q8(const float* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
+                        void* y_fp8, long long ldy8, float* scale_inv, float* mean, float* rstd, int rows, int d,
+                        float eps, void* stream);
+int sc_layernorm_bwd_q8(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
+                        const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
+                        long long lddbf, void* dres_fp8, long long ldd8, float* scale_inv, int accumulate,
+                        float* dgamma, float* dbeta, float* colsum, float* ws, int rows, int d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ attention
  * Fused multi-head self-attention on the packed in_proj output qkv[B*L, 3*H*dh] (q | k | v, head h at

@@ -9,7 +9,12 @@
 //     delayed scaling, nothing carried between steps;
 //   * the GEMM accumulates the raw e4m3 products in fp32 on the matrix cores (block scale 1.0) and multiplies
 //     accumulator (m, n) by a_scale_inv[m] * b_scale_inv[n] before bias / residual / GELU;
-//   * master weights stay fp32, the backward pass stays bf16 (weight and data gradients read the bf16 activations).
+//   * master weights stay fp32; weight gradients stay bf16 (they read the bf16 activations, which are still written);
+//   * round 3: the quantiser runs INSIDE the kernel that produces a complete row -- LayerNorm forward (A operand of the
+//     qkv / c_fc GEMMs) and LayerNorm backward (the residual gradient, A operand of the c_proj / out_proj data-gradient
+//     GEMMs, against a per-input-channel e4m3 copy of the transposed weight) -- see sc_norm.hip; operands whose rows are
+//     assembled by several workgroups (attention output, GELU output, dU, dqkv) stay bf16: a stand-alone quantiser pass
+//     over them costs more than the e4m3 GEMM gives back.
 #include "sc_gemm_common.h"
 
 namespace {
@@ -86,17 +91,17 @@ extern "C" int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long l
 
 extern "C" int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
                            const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
-                           const float* bias, const float* res, int ldres, void* stream) {
+                           const float* bias, const float* res, int ldres, const void* aux, int ldaux, void* stream) {
     SC_CHECK(M > 0 && N > 0 && K > 0 && (K % 128) == 0, "sc_gemm_fp8: K (%d) must be a positive multiple of 128", K);
     SC_CHECK((lda % 16) == 0 && (ldb % 16) == 0 && ((uintptr_t)A8 % 16) == 0 && ((uintptr_t)B8 % 16) == 0,
              "sc_gemm_fp8: operand rows must be 16-byte aligned (lda=%d ldb=%d)", lda, ldb);
     const bool f32out = (epi == SC_EPI_F32 || epi == SC_EPI_F32_BIAS_RES);
-    SC_CHECK(epi != SC_EPI_BF16_DGELU, "sc_gemm_fp8: forward epilogues only");
+    SC_CHECK(epi != SC_EPI_BF16_DGELU || (aux != nullptr && (ldaux % 8) == 0), "sc_gemm_fp8: the GELU' epilogue needs aux (ldaux %% 8 == 0)");
     SC_CHECK((N % (f32out ? 4 : 8)) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0, "sc_gemm_fp8: N=%d ldc=%d", N, ldc);
     GemmArgs g;
     g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
     g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
-    g.aux = nullptr; g.ldaux = 0; g.colsum = nullptr; g.tile_offset = 0;
+    g.aux = (const bf16*)aux; g.ldaux = ldaux; g.colsum = nullptr; g.tile_offset = 0;
     g.a_scale = a_scale_inv; g.b_scale = b_scale_inv;
     const int took = sc_gemm8p_fp8(epi, g, (hipStream_t)stream);
     SC_CHECK(took == 1, "sc_gemm_fp8: shape not supported (M=%d N=%d K=%d epi=%d)", M, N, K, epi);

@@ -944,6 +944,7 @@ int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st) {
     if (epi == SC_EPI_BF16_BIAS) return launch_f8<SC_EPI_BF16_BIAS>(g, nblocks, st);
     if (epi == SC_EPI_F32_BIAS_RES) return launch_f8<SC_EPI_F32_BIAS_RES>(g, nblocks, st);
     if (epi == SC_EPI_GELU_PAIR) return launch_f8<SC_EPI_GELU_PAIR>(g, nblocks, st);
+    if (epi == SC_EPI_BF16_DGELU) return launch_f8<SC_EPI_BF16_DGELU>(g, nblocks, st);
     if (epi == SC_EPI_F32) return launch_f8<SC_EPI_F32>(g, nblocks, st);
     return 0;
 }

@@ -22,11 +22,26 @@ SC_DEVICE void stbf4(bf16* p, f32x4 v) {
 }
 
 // ------------------------------------------------------------------ LayerNorm forward
-template <int NV>
+// fp8 path (sc_fp8.hip's recipe, fused): the row is complete in this wave's registers, so the kernel that normalises it
+// also emits its e4m3 copy with the row's power-of-two scale -- the forward GEMM's A operand -- and the separate
+// quantiser pass (read bf16 + write fp8 of the whole activation) disappears.
+SC_DEVICE unsigned ln_pack4_fp8(f32x4 v, float s) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0] * s, -448.f), 448.f), fminf(fmaxf(v[1] * s, -448.f), 448.f), 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2] * s, -448.f), 448.f), fminf(fmaxf(v[3] * s, -448.f), 448.f), w, true);
+    return (unsigned)w;
+}
+SC_DEVICE float ln_row_scale(float amax_lane) {
+    const float amax = sc_wave_max(amax_lane);
+    return amax > 0.f ? exp2f(floorf(log2f(448.0f / amax))) : 1.0f;
+}
+
+template <int NV, bool Q8>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      bf16* __restrict__ y, long long ldy, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int rows, int d, float eps) {
+                                                     float* __restrict__ rstd, int rows, int d, float eps,
+                                                     unsigned char* __restrict__ y8, long long ldy8,
+                                                     float* __restrict__ scale_inv) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -58,6 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (rstd) rstd[row] = rs;
     }
     bf16* yr = y + (long long)row * ldy;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
@@ -67,6 +83,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = (v[i][c] - mu) * rs * g[c] + b[c];
             stbf4(yr + e * 4, o);
+            if (Q8) {
+                v[i] = o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) amax = fmaxf(amax, fabsf(o[c]));
+            }
+        }
+    }
+    if (Q8) {
+        const float sc = ln_row_scale(amax);
+        if (lane == 0) scale_inv[row] = 1.0f / sc;
+        unsigned char* y8r = y8 + (long long)row * ldy8;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = i * 64 + lane;
+            if (e < nv) *reinterpret_cast<unsigned*>(y8r + e * 4) = ln_pack4_fp8(v[i], sc);
         }
     }
 }
@@ -74,13 +105,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ------------------------------------------------------------------ LayerNorm backward
 // dres_new = (accumulate ? dres : 0) + LNbwd(dy) (accumulate = -P: dres only holds rows r % P == 0); also emits the bf16 copy of dres_new (the A operand of
 // the next dgrad / wgrad GEMMs) and per-block partials of dgamma, dbeta and colsum(dres_new).
-template <int NV>
+template <int NV, bool Q8>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dres,
                                                      long long lddres, bf16* __restrict__ dres_bf, long long lddbf,
-                                                     float* __restrict__ partial, int rows, int d, int accumulate) {
+                                                     float* __restrict__ partial, int rows, int d, int accumulate,
+                                                     unsigned char* __restrict__ d8, long long ldd8,
+                                                     float* __restrict__ scale_inv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -118,6 +151,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         s2 = sc_wave_sum(s2) / (float)d;
         float* dr = dres + (long long)row * lddres;
         bf16* db = dres_bf ? dres_bf + (long long)row * lddbf : nullptr;
+        float amax = 0.f;
         // accumulate > 0: every row of dres holds an incoming residual gradient; accumulate = -P: only rows r with
         // r % P == 0 do (the class-token rows after a class-token-only block), the others start from zero and are not read
         const bool acc_row = accumulate > 0 || (accumulate < 0 && (row % (-accumulate)) == 0);
@@ -133,6 +167,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                 }
                 st4(dr + e * 4, o);
                 if (db) stbf4(db + e * 4, o);
+                if (Q8) {
+                    g[i] = o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) amax = fmaxf(amax, fabsf(o[c]));
+                }
+            }
+        }
+        if (Q8) {       // e4m3 copy of the new residual gradient + its row scale: the A operand of the fp8 dgrad GEMMs
+            const float sc = ln_row_scale(amax);
+            if (lane == 0) scale_inv[row] = 1.0f / sc;
+            unsigned char* d8r = d8 + (long long)row * ldd8;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = i * 64 + lane;
+                if (e < nv) *reinterpret_cast<unsigned*>(d8r + e * 4) = ln_pack4_fp8(g[i], sc);
             }
         }
     }
@@ -421,17 +470,38 @@ extern "C" int sc_cast_transpose_batched(const float* master, const void* mirror
     return 0;
 }
 
-extern "C" int sc_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, void* y,
-                                long long ldy, float* mean, float* rstd, int rows, int d, float eps, void* stream) {
+static int ln_fwd_launch(const float* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
+                         float* mean, float* rstd, int rows, int d, float eps, void* y8, long long ldy8, float* scale_inv,
+                         void* stream) {
     SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_fwd: bad shape rows=%d d=%d", rows, d);
     SC_CHECK((ldx % 4) == 0 && (ldy % 4) == 0, "sc_layernorm_fwd: row strides must be multiples of 4");
+    SC_CHECK(y8 == nullptr || (scale_inv != nullptr && (ldy8 % 4) == 0 && ldy8 >= d),
+             "sc_layernorm_fwd_q8: fp8 output needs scale_inv and a row stride that is a multiple of 4 (ldy8=%lld)", ldy8);
     const int nvv = (d / 4 + 63) / 64;
-#define SC_LN_FWD(NV) ln_fwd_kernel<NV><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps)
+#define SC_LN_FWD(NV)                                                                                                     \
+    do {                                                                                                                  \
+        if (y8) ln_fwd_kernel<NV, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                                 \
+            x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, (unsigned char*)y8, ldy8, scale_inv);           \
+        else ln_fwd_kernel<NV, false><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                                   \
+            x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, nullptr, 0, nullptr);                           \
+    } while (0)
     if (nvv <= 1) SC_LN_FWD(1); else if (nvv == 2) SC_LN_FWD(2); else if (nvv == 3) SC_LN_FWD(3);
     else if (nvv == 4) SC_LN_FWD(4); else SC_LN_FWD(8);
 #undef SC_LN_FWD
     SC_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sc_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, void* y,
+                                long long ldy, float* mean, float* rstd, int rows, int d, float eps, void* stream) {
+    return ln_fwd_launch(x, ldx, gamma, beta, y, ldy, mean, rstd, rows, d, eps, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int sc_layernorm_fwd_q8(const float* x, long long ldx, const float* gamma, const float* beta, void* y,
+                                   long long ldy, void* y_fp8, long long ldy8, float* scale_inv, float* mean, float* rstd,
+                                   int rows, int d, float eps, void* stream) {
+    SC_CHECK(y_fp8 != nullptr, "sc_layernorm_fwd_q8: fp8 output required");
+    return ln_fwd_launch(x, ldx, gamma, beta, y, ldy, mean, rstd, rows, d, eps, y_fp8, ldy8, scale_inv, stream);
 }
 
 extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
@@ -440,33 +510,58 @@ extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
     return (long long)nblk * 3 * d;
 }
 
-extern "C" int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
-                                const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
-                                long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum,
-                                float* ws, int rows, int d, void* stream) {
+static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
+                         const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
+                         long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum, float* ws, int rows,
+                         int d, void* d8, long long ldd8, float* scale_inv, void* stream) {
     SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_bwd: bad shape rows=%d d=%d", rows, d);
     SC_CHECK(ws != nullptr, "sc_layernorm_bwd: workspace required");
+    SC_CHECK(d8 == nullptr || (scale_inv != nullptr && (ldd8 % 4) == 0 && ldd8 >= d),
+             "sc_layernorm_bwd_q8: fp8 output needs scale_inv and a row stride that is a multiple of 4 (ldd8=%lld)", ldd8);
     int nblk = (rows + 3) / 4;
     if (nblk > 1024) nblk = 1024;
     const size_t lds = (size_t)4 * 3 * d * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int nvv = (d / 4 + 63) / 64;
-#define SC_LN_BWD(NV)                                                                                              \
-    do {                                                                                                           \
-        if (lds > 48 * 1024)                                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NV>),                          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-        ln_bwd_kernel<NV><<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres,  \
-                                                  (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate);               \
+#define SC_LN_BWD_Q(NV, Q)                                                                                              \
+    do {                                                                                                                \
+        if (lds > 48 * 1024)                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, Q>),                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        ln_bwd_kernel<NV, Q><<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres,    \
+                                                     (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate,                  \
+                                                     (unsigned char*)d8, ldd8, scale_inv);                              \
+    } while (0)
+#define SC_LN_BWD(NV)                                                                                                   \
+    do {                                                                                                                \
+        if (d8) SC_LN_BWD_Q(NV, true); else SC_LN_BWD_Q(NV, false);                                                     \
     } while (0)
     if (nvv <= 1) SC_LN_BWD(1); else if (nvv == 2) SC_LN_BWD(2); else if (nvv == 3) SC_LN_BWD(3);
     else if (nvv == 4) SC_LN_BWD(4); else SC_LN_BWD(8);
 #undef SC_LN_BWD
+#undef SC_LN_BWD_Q
     SC_LAUNCH_CHECK();
     if (dgamma == nullptr) return 0;      // deferred: the caller runs sc_layernorm_bwd_reduce (possibly on another stream)
     colvec_finalize_kernel<<<(3 * d + 63) / 64, 1024, 0, st>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
     SC_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
+                                const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
+                                long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum,
+                                float* ws, int rows, int d, void* stream) {
+    return ln_bwd_launch(dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dres_bf16, lddbf, accumulate, dgamma, dbeta,
+                         colsum, ws, rows, d, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int sc_layernorm_bwd_q8(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
+                                   const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
+                                   long long lddbf, void* dres_fp8, long long ldd8, float* scale_inv, int accumulate,
+                                   float* dgamma, float* dbeta, float* colsum, float* ws, int rows, int d, void* stream) {
+    SC_CHECK(dres_fp8 != nullptr, "sc_layernorm_bwd_q8: fp8 output required");
+    return ln_bwd_launch(dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dres_bf16, lddbf, accumulate, dgamma, dbeta,
+                         colsum, ws, rows, d, dres_fp8, ldd8, scale_inv, stream);
 }
 
 extern "C" int sc_layernorm_bwd_reduce(const float* ws, int rows, int d, float* dgamma, float* dbeta, float* colsum,

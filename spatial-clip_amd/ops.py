@@ -140,8 +140,20 @@ def attn_bwd(qkv, out, dout, lse, B: int, L: int, H: int, dh: int, causal: bool 
 
 # ------------------------------------------------------------------------------------------ norms
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows: int, d: int, ldx: Optional[int] = None,
-                  ldy: Optional[int] = None, eps: float = 1e-5):
+                  ldy: Optional[int] = None, eps: float = 1e-5, q8: Optional[torch.Tensor] = None,
+                  q8_scale_inv: Optional[torch.Tensor] = None):
+    """``q8`` (uint8 [rows, d]) + ``q8_scale_inv`` (fp32 [rows]): also emit the e4m3 copy of the output with its
+    per-row power-of-two scale (the fp8 forward GEMM's A operand) from the same kernel."""
     _req(x, torch.float32, "x"); _req(y, torch.bfloat16, "y")
+    if q8 is not None:
+        if q8.dtype != torch.uint8 or not q8.is_cuda or q8.stride(-1) != 1:
+            raise TypeError("layernorm_fwd: q8 must be a device uint8 matrix")
+        _req(q8_scale_inv, torch.float32, "q8_scale_inv")
+        check(_lib.lib().sc_layernorm_fwd_q8(x.data_ptr(), ldx if ldx is not None else d, gamma.data_ptr(),
+                                             beta.data_ptr(), y.data_ptr(), ldy if ldy is not None else d, q8.data_ptr(),
+                                             q8.stride(0), q8_scale_inv.data_ptr(), _ptr(mean), _ptr(rstd), rows, d, eps,
+                                             _stream()), "sc_layernorm_fwd_q8")
+        return y
     check(_lib.lib().sc_layernorm_fwd(x.data_ptr(), ldx if ldx is not None else d, gamma.data_ptr(), beta.data_ptr(),
                                       y.data_ptr(), ldy if ldy is not None else d, _ptr(mean), _ptr(rstd), rows, d, eps,
                                       _stream()), "sc_layernorm_fwd")
@@ -158,7 +170,8 @@ def gelu_bf16(u: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, colsum, rows: int, d: int, *,
-                  accumulate, lddy=None, ldx=None, lddres=None, lddbf=None, ws=None, defer_reduce: bool = False):
+                  accumulate, lddy=None, ldx=None, lddres=None, lddbf=None, ws=None, defer_reduce: bool = False,
+                  q8: Optional[torch.Tensor] = None, q8_scale_inv: Optional[torch.Tensor] = None):
     """``accumulate``: False / True, or a negative int -P: only rows r % P == 0 of ``dres`` carry an incoming gradient.
     ``defer_reduce``: leave the per-block partial sums of dgamma / dbeta / colsum in ``ws`` (caller-owned, at least
     layernorm_bwd_ws_floats floats) and finish them with layernorm_bwd_reduce -- e.g. on the weight-gradient stream."""
@@ -168,6 +181,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, cols
         if defer_reduce:
             raise _lib.SpatialClipHipError("layernorm_bwd: defer_reduce needs a caller-owned workspace")
         ws = workspace(l.sc_layernorm_bwd_ws_floats(rows, d), dy.device, "ln")
+    if q8 is not None:          # e4m3 copy of the new residual gradient + per-row 1/scale (A operand of the fp8 dgrad GEMMs)
+        if q8.dtype != torch.uint8 or not q8.is_cuda or q8.stride(-1) != 1:
+            raise TypeError("layernorm_bwd: q8 must be a device uint8 matrix")
+        _req(q8_scale_inv, torch.float32, "q8_scale_inv")
+        check(l.sc_layernorm_bwd_q8(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
+                                    gamma.data_ptr(), dres.data_ptr(), lddres or d, _ptr(dres_bf16), lddbf or d,
+                                    q8.data_ptr(), q8.stride(0), q8_scale_inv.data_ptr(), int(accumulate),
+                                    None if defer_reduce else dgamma.data_ptr(), dbeta.data_ptr(), _ptr(colsum),
+                                    ws.data_ptr(), rows, d, _stream()), "sc_layernorm_bwd_q8")
+        return
     check(l.sc_layernorm_bwd(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
                              gamma.data_ptr(), dres.data_ptr(), lddres or d, _ptr(dres_bf16), lddbf or d,
                              int(accumulate), None if defer_reduce else dgamma.data_ptr(), dbeta.data_ptr(), _ptr(colsum),
@@ -459,8 +482,10 @@ def quantize_rows_fp8(src: torch.Tensor, dst: Optional[torch.Tensor] = None, sca
 
 def gemm_fp8(epi: int, a8: torch.Tensor, a_scale_inv: torch.Tensor, b8: torch.Tensor, b_scale_inv: torch.Tensor,
              out: torch.Tensor, *, M: int, N: int, K: int, out2: Optional[torch.Tensor] = None,
-             bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C[M,N] = dequant(A8[M,K] . B8[N,K]^T) with the bf16 GEMM's forward epilogues (see sc_gemm_fp8)."""
+             bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+             aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C[M,N] = dequant(A8[M,K] . B8[N,K]^T) with the bf16 GEMM's epilogues (see sc_gemm_fp8); ``aux`` = the pre-GELU
+    tensor of EPI_BF16_DGELU (the c_proj data-gradient GEMM)."""
     for t_, n in ((a8, "a8"), (b8, "b8")):
         if not t_.is_cuda or t_.dtype != torch.uint8 or t_.stride(-1) != 1:
             raise TypeError(f"gemm_fp8: {n} must be a device uint8 (e4m3 bytes) matrix")
@@ -474,7 +499,8 @@ def gemm_fp8(epi: int, a8: torch.Tensor, a_scale_inv: torch.Tensor, b8: torch.Te
     rc = _lib.lib().sc_gemm_fp8(epi, a8.data_ptr(), a8.stride(0), a_scale_inv.data_ptr(), b8.data_ptr(), b8.stride(0),
                                 b_scale_inv.data_ptr(), M, N, K, out.data_ptr(), out.stride(0), _ptr(out2),
                                 out2.stride(0) if out2 is not None else 0, _ptr(bias), _ptr(res),
-                                res.stride(0) if res is not None else 0, _stream())
+                                res.stride(0) if res is not None else 0, _ptr(aux),
+                                aux.stride(0) if aux is not None else 0, _stream())
     if ev is not None:
         ev[1].record()
         KERNEL_EVENTS.append(("gemm_nt_fp8", 2.0 * M * N * K, ev))

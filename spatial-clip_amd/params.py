@@ -52,6 +52,8 @@ class LinearCopy:
     wb: Optional[torch.Tensor] = None
     w8: Optional[torch.Tensor] = None       # fp8 path: e4m3 bytes [N_out, K_in] + per-output-channel dequantisation factors
     w8s: Optional[torch.Tensor] = None
+    wb8: Optional[torch.Tensor] = None      # fp8 data-gradient path: e4m3 bytes of wb [K_in, N_out] + per-input-channel factors
+    wb8s: Optional[torch.Tensor] = None
 
 
 def _block_specs(prefix: str, d: int, mlp: int) -> List[ParamSpec]:
@@ -237,11 +239,17 @@ class ParamStore:
             if self.fp8:
                 if dd % 128 or mlp % 128:
                     raise ValueError(f"fp8 path needs block widths that are multiples of 128 (got {dd} / {mlp})")
-                for leaf, n_out, k_in in (("attn.in_proj_weight", 3 * dd, dd), ("attn.out_proj.weight", dd, dd),
-                                          ("mlp.c_fc.weight", mlp, dd), ("mlp.c_proj.weight", dd, mlp)):
+                # e4m3 operands exist only where the quantiser of the OTHER operand is fused into the kernel that
+                # produces it (towers.TransformerStack): forward qkv / c_fc (A = LayerNorm output), data gradients of
+                # c_proj / out_proj (A = the residual gradient LayerNorm backward emits; B = the transposed weight)
+                for leaf, n_out, k_in in (("attn.in_proj_weight", 3 * dd, dd), ("mlp.c_fc.weight", mlp, dd)):
                     c = self.copies[prefix + leaf]
                     c.w8 = torch.zeros((n_out, k_in), dtype=torch.uint8, device=self.device)
                     c.w8s = torch.ones(n_out, dtype=torch.float32, device=self.device)
+                for leaf, n_out, k_in in (("attn.out_proj.weight", dd, dd), ("mlp.c_proj.weight", dd, mlp)):
+                    c = self.copies[prefix + leaf]
+                    c.wb8 = torch.zeros((k_in, n_out), dtype=torch.uint8, device=self.device)
+                    c.wb8s = torch.ones(k_in, dtype=torch.float32, device=self.device)
 
         for i in range(v.layers):
             block(f"visual.transformer.resblocks.{i}.", d, int(d * v.mlp_ratio))
@@ -295,6 +303,8 @@ class ParamStore:
             for c in self.copies.values():
                 if c.w8 is not None:
                     ops.quantize_rows_fp8(self.p(c.name).view(c.n_out, c.k_in), c.w8, c.w8s)
+                if c.wb8 is not None:                     # rows of the transposed bf16 copy = input channels
+                    ops.quantize_rows_fp8(c.wb, c.wb8, c.wb8s)
         for c in self.copies.values():
             if not c.stored_kn and not c.wf_is_view:      # K-padded forward operand (gene.fc1, conv1 at patch 14)
                 ops.cast_pad_bf16(self.p(c.name).view(c.n_out, c.k_in), c.wf, c.n_out, c.k_in, c.k_pad,

@@ -79,16 +79,20 @@ class TransformerStack:
             return self.bufs.get(f"{kind}.rc{i & 1}", shape, BF16)
         return self.bufs.get(f"{kind}.{i}", shape, BF16)
 
-    def _linear_fwd(self, epi: int, x: torch.Tensor, name: str, out: torch.Tensor, *, M: int, N: int, K: int, **kw):
-        """One forward Linear of a full-width block: bf16 MFMA GEMM, or (fp8 path) per-row e4m3 quantisation of the
-        activation rows followed by the fp8 MFMA GEMM against the per-channel-quantised weight."""
+    def _linear_fwd(self, epi: int, x: torch.Tensor, name: str, out: torch.Tensor, *, M: int, N: int, K: int, q8=None,
+                    **kw):
+        """One forward Linear of a full-width block: the bf16 MFMA GEMM, or -- fp8 path, when the producer of ``x`` has
+        also emitted its e4m3 copy ``q8 = (bytes, scale_inv)`` and the weight has an e4m3 copy -- the fp8 MFMA GEMM."""
         cp = self.s.copies[name]
-        if not self.fp8:
+        if q8 is None or cp.w8 is None:
             return ops.gemm(ops.NT, epi, x, cp.wf, out, M=M, N=N, K=K, **kw)
-        q8 = self.bufs.get(f"q8.{K}", (M, K), torch.uint8)
-        qs = self.bufs.get("q8.scale", (M,), F32)
-        ops.quantize_rows_fp8(x, q8, qs)
-        return ops.gemm_fp8(epi, q8, qs, cp.w8, cp.w8s, out, M=M, N=N, K=K, **kw)
+        return ops.gemm_fp8(epi, q8[0], q8[1], cp.w8, cp.w8s, out, M=M, N=N, K=K, **kw)
+
+    def _q8(self, tag: str, M: int, K: int):
+        """(e4m3 bytes [M, K], scale_inv [M]) scratch for a fused quantiser output, or None off the fp8 path."""
+        if not self.fp8:
+            return None
+        return self.bufs.get(f"q8.{tag}", (M, K), torch.uint8), self.bufs.get(f"q8s.{tag}", (M,), F32)
 
     def _n(self, i: int, leaf: str) -> str:
         return f"{self.prefix}{i}.{leaf}"
@@ -112,10 +116,12 @@ class TransformerStack:
             a1 = self._act("a1", i, (M, d))
             m1 = bf.get(f"m1.{i}", (M,), F32)
             r1 = bf.get(f"r1.{i}", (M,), F32)
-            ops.layernorm_fwd(x, s.p(self._n(i, "ln_1.weight")), s.p(self._n(i, "ln_1.bias")), a1, m1, r1, M, d)
+            qa = self._q8("a", M, d)            # fp8: LayerNorm also emits the e4m3 copy + row scales (rotating scratch)
+            ops.layernorm_fwd(x, s.p(self._n(i, "ln_1.weight")), s.p(self._n(i, "ln_1.bias")), a1, m1, r1, M, d,
+                              q8=qa and qa[0], q8_scale_inv=qa and qa[1])
             qkv = bf.get(f"qkv.{i}", (M, 3 * d), BF16)
             self._linear_fwd(ops.EPI_BF16_BIAS, a1, self._n(i, "attn.in_proj_weight"), qkv,
-                             M=M, N=3 * d, K=d, bias=s.p(self._n(i, "attn.in_proj_bias")))
+                             M=M, N=3 * d, K=d, bias=s.p(self._n(i, "attn.in_proj_bias")), q8=qa)
             o = bf.get(f"o.{i}", (M, d), BF16)
             lse = bf.get(f"lse.{i}", (B, H, L), F32)
             if self.cls_only_last and i == self.layers - 1:
@@ -127,11 +133,12 @@ class TransformerStack:
             a2 = self._act("a2", i, (M, d))
             m2 = bf.get(f"m2.{i}", (M,), F32)
             r2 = bf.get(f"r2.{i}", (M,), F32)
-            ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2, m2, r2, M, d)
+            ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2, m2, r2, M, d,
+                              q8=qa and qa[0], q8_scale_inv=qa and qa[1])
             u = bf.get(f"u.{i}", (M, mlp), BF16)
             h = self._act("h", i, (M, mlp))
             self._linear_fwd(ops.EPI_GELU_PAIR, a2, self._n(i, "mlp.c_fc.weight"), u,
-                             M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)
+                             M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h, q8=qa)
             xo = bf.get(f"xout.{i}", (M, d), F32)
             self._linear_fwd(ops.EPI_F32_BIAS_RES, h, self._n(i, "mlp.c_proj.weight"), xo,
                              M=M, N=d, K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
@@ -204,9 +211,12 @@ class TransformerStack:
         ops.gemm(ops.NT, ops.EPI_BF16, dqkv, cp("attn.in_proj_weight").wb, dA, M=M, N=d, K=3 * d)
         dres_bf = bf.get("dres_bf.0", (M, d), BF16)
         prev_bias = s.g(self._n(i - 1, "mlp.c_proj.bias")) if i > 0 else None
+        qg = self._q8("g", M, d)
         ops.layernorm_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
                           s.p(self._n(i, "ln_1.weight")), dres, dres_bf, g("ln_1.weight"), g("ln_1.bias"),
-                          prev_bias, M, d, accumulate=-L)       # only the class-token rows carry a residual gradient
+                          prev_bias, M, d, accumulate=-L,       # only the class-token rows carry a residual gradient
+                          q8=qg and qg[0], q8_scale_inv=qg and qg[1])
+        self._g_q8 = qg
         return dres, dres_bf
 
     # -------------------------------------------------------------------------------- backward
@@ -223,6 +233,7 @@ class TransformerStack:
         s, d, H, dh, mlp = self.s, self.d, self.H, self.dh, self.mlp
         B, L, M = self.B, self.L, self.M
         bf = self.bufs
+        cp_of = lambda name: s.copies[name]
         # measured on one MI355X (ViT-B/16, B = 256, interleaved runs): 37.8 vs 38.4 ms/step with the side stream
         # (the weight-gradient workgroups take the CUs the 2.3-round dgrad GEMMs leave idle); SC_OVERLAP=0 pins one stream
         overlap = os.environ.get("SC_OVERLAP", "1") == "1"
@@ -260,24 +271,41 @@ class TransformerStack:
         ln_ws = [bf.get(f"ln_ws.{k}", (ln_ws_n,), F32) for k in range(4)] if overlap else None
         ln_pos = [0]
 
+        # fp8 path: LayerNorm backward also emits the e4m3 copy (+ row scales) of the residual gradient it has just
+        # formed -- the A operand of the next data-gradient GEMM (c_proj after LN1 of the block above, out_proj after
+        # LN2).  Producer and consumer are both on the chain stream, back to back: ONE scratch is enough.
+        qg = self._q8("g", M, d)
+
         def ln_bwd(dy, x, mean, rstd, gamma, g_bf, dgamma, dbeta, colsum) -> None:
+            q8kw = dict(q8=qg[0], q8_scale_inv=qg[1]) if qg is not None else {}
             if not overlap:
-                ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, g_bf, dgamma, dbeta, colsum, M, d, accumulate=True)
+                ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, g_bf, dgamma, dbeta, colsum, M, d, accumulate=True, **q8kw)
                 return
             ws = ln_ws[ln_pos[0] % 4]
             ln_pos[0] += 1
             before_write(ws)
             ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, g_bf, dgamma, dbeta, colsum, M, d, accumulate=True,
-                              ws=ws, defer_reduce=True)
+                              ws=ws, defer_reduce=True, **q8kw)
             on_side(lambda: ops.layernorm_bwd_reduce(ws, dgamma, dbeta, colsum, M, d), (ws,))
+
+        def dgrad(epi, g_bf, name, out, *, N, K, have_q8, **kw) -> None:
+            """Data-gradient GEMM out[M, N] = g[M, K] . W (NT against the transposed weight copy): e4m3 operands when the
+            residual gradient's e4m3 copy is live in ``qg`` and the weight has one, bf16 otherwise."""
+            c = cp_of(name)
+            if have_q8 and qg is not None and c.wb8 is not None:
+                ops.gemm_fp8(epi, qg[0], qg[1], c.wb8, c.wb8s, out, M=M, N=N, K=K, **kw)
+            else:
+                ops.gemm(ops.NT, epi, g_bf, c.wb, out, M=M, N=N, K=K, **kw)
 
         dA = bf.get("dA", (M, d), BF16)
         dO = bf.get("dO", (M, d), BF16)
         delta = bf.get("delta", (B, H, L), F32)
         top = self.layers
+        g_has_q8 = False                   # is the e4m3 copy of the current residual gradient in qg?
         if self.cls_only_last:
             dres, dres_bf = self._backward_last_cls(dres, dres_bf, on_side)
             top = self.layers - 1
+            g_has_q8 = qg is not None
             if on_layer_done is not None:
                 on_side(lambda: on_layer_done(self.layers - 1), ())
         ring = [dres_bf, bf.get("dres_bf.1", (M, d), BF16), bf.get("dres_bf.2", (M, d), BF16)]
@@ -296,7 +324,7 @@ class TransformerStack:
                 ops.colsum_bf16(g0, M, d, g("mlp.c_proj.bias"))
             # ---- MLP branch: x_out = xmid + c_proj(gelu(c_fc(ln_2(xmid))))
             before_write(dU)
-            ops.gemm(ops.NT, ops.EPI_BF16_DGELU, g0, cp("mlp.c_proj.weight").wb, dU, M=M, N=mlp, K=d, aux=u)
+            dgrad(ops.EPI_BF16_DGELU, g0, self._n(i, "mlp.c_proj.weight"), dU, N=mlp, K=d, have_q8=g_has_q8, aux=u)
 
             def w_mlp(g0=g0, h=h, dU=dU, a2=a2, g=g):
                 ops.gemm(ops.TN, ops.EPI_F32, g0, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M, splitk=_splitk_for(d, mlp, M))
@@ -317,7 +345,7 @@ class TransformerStack:
             ln_bwd(dA, xmid, bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32),
                    s.p(self._n(i, "ln_2.weight")), g1, g("ln_2.weight"), g("ln_2.bias"), g("attn.out_proj.bias"))
             # ---- attention branch: xmid = x_in + out_proj(attn(in_proj(ln_1(x_in))))
-            ops.gemm(ops.NT, ops.EPI_BF16, g1, cp("attn.out_proj.weight").wb, dO, M=M, N=d, K=d)
+            dgrad(ops.EPI_BF16, g1, self._n(i, "attn.out_proj.weight"), dO, N=d, K=d, have_q8=qg is not None)
             before_write(dqkv)
             ops.attn_bwd(qkv, o, dO, lse, B, L, H, dh, self.causal, dqkv=dqkv, delta=delta)
 
@@ -338,6 +366,7 @@ class TransformerStack:
             before_write(g2)
             ln_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
                    s.p(self._n(i, "ln_1.weight")), g2, g("ln_1.weight"), g("ln_1.bias"), prev_bias)
+            g_has_q8 = qg is not None
             if on_layer_done is not None:
                 on_side(lambda i=i: on_layer_done(i), ())     # the bucket all-reduce follows the side stream
         if overlap:

@@ -177,3 +177,71 @@ def test_fp8_model_step_against_fp32_oracle_stated_tolerance():
     with pytest.raises(ValueError, match="multiples of 128"):
         net.SpatialClipNet("custom", None, model_cfg=mc.ModelCfg(32, mc.VisionCfg(32, 8, 64, 2, 32), None, mc.GeneCfg(200, 64)),
                            precision="fp8")
+
+
+# ---------------------------------------------------------------------------------------------- round 3: fused quantisers
+@pytest.mark.parametrize("rows,d", [(197 * 3, 768), (257 * 2, 1024), (80, 512), (33, 128)])
+def test_layernorm_forward_and_backward_emit_the_e4m3_copy(rows, d):
+    """sc_layernorm_fwd_q8 / sc_layernorm_bwd_q8: the bf16 / fp32 outputs are bit-identical to the plain kernels', the
+    e4m3 copy is the per-row power-of-two quantisation of the fp32 value the kernel holds (row scale in the top binade of
+    e4m3, dequantised value within e4m3 half-ulp 2^-4 of the bf16 output's fp32 source)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn(rows, d, generator=g) * torch.logspace(-1, 1, rows).view(-1, 1)).cuda()
+    gamma, beta = (1.0 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+    y0 = torch.empty((rows, d), dtype=torch.bfloat16, device="cuda"); y1 = torch.empty_like(y0)
+    m0, r0, m1, r1 = (torch.empty(rows, device="cuda") for _ in range(4))
+    ops.layernorm_fwd(x, gamma, beta, y0, m0, r0, rows, d)
+    q8 = torch.zeros((rows, d), dtype=torch.uint8, device="cuda"); sinv = torch.zeros(rows, device="cuda")
+    ops.layernorm_fwd(x, gamma, beta, y1, m1, r1, rows, d, q8=q8, q8_scale_inv=sinv)
+    assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    ref = torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5)
+    s = 1.0 / sinv
+    assert torch.equal(torch.log2(s).round(), torch.log2(s))
+    top = ref.abs().amax(1) * s
+    assert bool((top <= 448.0 * 1.001).all()) and bool((top > 224.0 * 0.999).all())
+    back = deq(q8, sinv)
+    assert bool(((back - ref).abs() <= ref.abs() * 2.0 ** -4 + (sinv * 2.0 ** -9)[:, None] + 1e-5).all())
+    # backward
+    dy = torch.randn(rows, d, generator=g).bfloat16().cuda()
+    outs = []
+    for fused in (False, True):
+        dres = torch.randn(rows, d, generator=torch.Generator().manual_seed(5)).cuda()
+        gbf = torch.empty((rows, d), dtype=torch.bfloat16, device="cuda")
+        dg, db, cs = (torch.empty(d, device="cuda") for _ in range(3))
+        kw = {}
+        if fused:
+            q8b = torch.zeros((rows, d), dtype=torch.uint8, device="cuda"); sb = torch.zeros(rows, device="cuda")
+            kw = dict(q8=q8b, q8_scale_inv=sb)
+        ops.layernorm_bwd(dy, x, m0, r0, gamma, dres, gbf, dg, db, cs, rows, d, accumulate=True, **kw)
+        outs.append((dres, gbf, dg, db, cs))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    dres = outs[1][0]
+    s = 1.0 / sb
+    top = dres.abs().amax(1) * s
+    assert bool((top <= 448.0).all()) and bool((top > 224.0).all())
+    want = (dres * s[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q8b, want)                       # same bits as torch's e4m3fn rounding of the fp32 result
+
+
+def test_gemm_fp8_dgelu_epilogue_exact_inputs():
+    """The data-gradient form (c_proj dgrad: e4m3 residual gradient x e4m3 transposed weight, GELU' epilogue reading the
+    bf16 pre-activation): on exactly representable operands the fp8 kernel and the bf16 kernel see the same fp32
+    accumulators, so their outputs must be bit-identical."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 197 * 4 + 5, 1024, 256
+    a = torch.randint(-7, 8, (M, K), generator=g).float() * torch.pow(2.0, torch.randint(-2, 3, (M, 1), generator=g).float())
+    b = torch.randint(-7, 8, (N, K), generator=g).float() * torch.pow(2.0, torch.randint(-3, 1, (N, 1), generator=g).float())
+    aux = torch.randn(M, N, generator=g).bfloat16().cuda()
+    a8, sa = ops.quantize_rows_fp8(a.cuda())
+    b8, sb = ops.quantize_rows_fp8(b.cuda())
+    o8 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda"); ob = torch.empty_like(o8)
+    ops.gemm_fp8(ops.EPI_BF16_DGELU, a8, sa, b8, sb, o8, M=M, N=N, K=K, aux=aux)
+    ops.gemm(ops.NT, ops.EPI_BF16_DGELU, a.bfloat16().cuda(), b.bfloat16().cuda(), ob, M=M, N=N, K=K, aux=aux)
+    assert torch.equal(o8, ob)
+    x = aux.float().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref = ((a.double() @ b.double().t()).float() * x.grad)
+    torch.testing.assert_close(o8.float().cpu(), ref.to(torch.bfloat16).float(), atol=3e-2, rtol=3e-2)
