@@ -117,10 +117,12 @@ def test_gemm_fp8_accuracy_on_activation_like_data():
 
 
 def test_fp8_model_step_against_fp32_oracle_stated_tolerance():
-    """The stated bound of the fp8 path: with e4m3 forward GEMMs in both towers' blocks the loss stays
-    within 1e-2 and the unit-norm features within 4e-2 (max abs) of the fp32 oracle on identical weights and batch
-    (measured: 1.6e-3 / 8e-3 here, 3.0e-3 / 2.8e-2 at ViT-L/14 B=256); gradients (bf16 backward through fp8-perturbed
-    activations) within 25 % of each tensor's max-abs (worst tensor measured 20 %); optimiser steps still reduce the loss."""
+    """The stated bound of the fp8 path: with e4m3 qkv / c_fc forward GEMMs and e4m3 c_proj / out_proj
+    data-gradient GEMMs in both towers' blocks the loss stays within 1e-2 and the unit-norm features within 4e-2 (max abs)
+    of the fp32 oracle on identical weights and batch (measured: 1.5e-3 / 5.9e-3 on this width-128 toy, 5.7e-5 / 4.6e-3 at
+    full ViT-L/14 geometry, tests/test_gpu_fullsize.py); gradients within 35 % of each tensor's max-abs on the toy (worst
+    tensor measured 26 %: K = 128 averages only 128 e4m3 round-offs per output; the e4m3 data gradients added 6 points to
+    round 2's 20 %); optimiser steps still reduce the loss."""
     import functools
     from oracle import spatial_clip_oracle as O
     import spatial_clip_amd  # noqa: F401
@@ -149,13 +151,15 @@ def test_fp8_model_step_against_fp32_oracle_stated_tolerance():
     dft = float((out["text_features"].cpu() - f["text_features"].detach()).abs().max())
     out["loss"].backward()
     torch.cuda.synchronize()
-    worst = 0.0
+    worst, worst_k = 0.0, ""
     for k in params:
         if p[k].grad is None or float(p[k].grad.abs().max()) == 0:
             continue
-        worst = max(worst, float((n8.store.g(k).cpu() - p[k].grad).abs().max() / p[k].grad.abs().max()))
-    print(f"[fp8 model] |d loss| = {dl:.2e}, max |d feature| image {dfi:.2e} text {dft:.2e}, worst grad rel err {worst:.3f}")
-    assert dl < 1e-2 and dfi < 4e-2 and dft < 4e-2 and worst < 0.25
+        e = float((n8.store.g(k).cpu() - p[k].grad).abs().max() / p[k].grad.abs().max())
+        if e > worst:
+            worst, worst_k = e, k
+    print(f"[fp8 model] |d loss| = {dl:.2e}, max |d feature| image {dfi:.2e} text {dft:.2e}, worst grad rel err {worst:.3f} ({worst_k})")
+    assert dl < 1e-2 and dfi < 4e-2 and dft < 4e-2 and worst < 0.35
 
     class T:
         max_steps, max_epochs, estimated_stepping_batches = 20, None, 20
