@@ -45,8 +45,7 @@ SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
 // XOR-swizzled by row so the 8-B writes (2-way at worst) and 16-B reads spread over the banks.
 //   BF16 / BF16_BIAS: C = bf16(acc (+ bias));  GELU_PAIR: C = u = bf16(acc + bias), C2 = bf16(gelu(float(u))).
 template <int EPI>
-SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* strip, int row0, int col0, int lane,
-                                 int row_end) {          // rows >= row_end are not stored (g.M, or the end of a short tile)
+SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* strip, int row0, int col0, int lane) {
     const int li = lane & 15, lg = lane >> 4;
     constexpr bool kBias = (EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR);
     f32x4 bj[4];
@@ -79,7 +78,7 @@ SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* st
             const int r = s4 * 8 + rr;
             const u32x4 u = *reinterpret_cast<const u32x4*>(strip + r * 128 + ((rc ^ (r & 7)) << 4));
             const int grow = row0 + p * 32 + r;
-            if (grow < row_end && gcol < g.N) {
+            if (grow < g.M && gcol < g.N) {
                 *reinterpret_cast<u32x4*>(C + (size_t)grow * g.ldc + gcol) = u;
                 if (EPI == SC_EPI_GELU_PAIR) {
                     union { u32x4 w; bf16x8 h; } x;
@@ -111,11 +110,9 @@ struct Stager {
 };
 
 // One phase of K tile `t` (ring parity D):  PH = 1..4  <->  quadrant (0,0) (0,1) (1,1) (1,0).
-// SHORT: the second 64-row half of this wave's tile has only `nii` (0..4, wave-uniform) of its four row fragments
-// (short tiles, GemmArgs::f0 / f1): the other fragments are neither read from LDS nor multiplied.
-template <int D, int PH, bool SHORT>
+template <int D, int PH>
 SC_DEVICE void phase(char* smem, const Stager& S, int t, const int (&a_off)[2], const int (&b_off)[2], bf16x8 (&a)[8],
-                     bf16x8 (&b0)[4], bf16x8 (&b1)[4], f32x4 (&acc)[8][4], int nii) {
+                     bf16x8 (&b0)[4], bf16x8 (&b1)[4], f32x4 (&acc)[8][4]) {
     // ---- load section: fragments of this quadrant that are not in registers yet ----
     if (PH == 1) {
 #pragma unroll
@@ -137,8 +134,7 @@ SC_DEVICE void phase(char* smem, const Stager& S, int t, const int (&a_off)[2], 
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
-                if (!SHORT || PH == 1 || ii < nii)
-                    a[kk * 4 + ii] = *reinterpret_cast<const bf16x8*>(smem + sl + a_off[kk] + ii * 2048);
+                a[kk * 4 + ii] = *reinterpret_cast<const bf16x8*>(smem + sl + a_off[kk] + ii * 2048);
     }
     // ---- stage the half-tile six positions ahead (consumption order A0 B0 B1 A1) ----
     constexpr int q = (PH + 1) & 3;
@@ -161,29 +157,27 @@ SC_DEVICE void phase(char* smem, const Stager& S, int t, const int (&a_off)[2], 
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            if (SHORT && mi == 1 && ii >= nii) continue;       // wave-uniform: scalar branch around the fragment's MFMAs
+        for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
                 acc[mi * 4 + ii][nj * 2 + jj] =
                     sc_mfma16(nj ? b1[kk * 2 + jj] : b0[kk * 2 + jj], a[kk * 4 + ii], acc[mi * 4 + ii][nj * 2 + jj]);
-        }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int D, bool SHORT>
+template <int D>
 SC_DEVICE void ktile(char* smem, const Stager& S, int t, const int (&a_off)[2], const int (&b_off)[2], bf16x8 (&a)[8],
-                     bf16x8 (&b0)[4], bf16x8 (&b1)[4], f32x4 (&acc)[8][4], int nii) {
-    phase<D, 1, SHORT>(smem, S, t, a_off, b_off, a, b0, b1, acc, nii);
-    phase<D, 2, SHORT>(smem, S, t, a_off, b_off, a, b0, b1, acc, nii);
-    phase<D, 3, SHORT>(smem, S, t, a_off, b_off, a, b0, b1, acc, nii);
-    phase<D, 4, SHORT>(smem, S, t, a_off, b_off, a, b0, b1, acc, nii);
+                     bf16x8 (&b0)[4], bf16x8 (&b1)[4], f32x4 (&acc)[8][4]) {
+    phase<D, 1>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+    phase<D, 2>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+    phase<D, 3>(smem, S, t, a_off, b_off, a, b0, b1, acc);
+    phase<D, 4>(smem, S, t, a_off, b_off, a, b0, b1, acc);
 }
 
-template <int EPI, bool SHORT>
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
@@ -197,10 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
     idx /= g.ntn;
     const int tm = idx % g.ntm;
     const int z = idx / g.ntm;
-    // short tiles: tile stride g.tile_m = 16 (f0 + f1) rows, the second M-wave group starts 16 f0 rows into the tile
-    const int wave_m = SHORT ? g.f0 * 16 : 128;
-    const int m0 = tm * (SHORT ? g.tile_m : BM), n0 = tn * BN;
-    const int nii = SHORT ? __builtin_amdgcn_readfirstlane((wr ? g.f1 : g.f0) - 4) : 4;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
@@ -213,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
         const int lc = (lane & 7) ^ ((r >> 1) & 7);              // logical 16-byte chunk stored at physical lane&7
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int ga = min(m0 + (r >> 6) * wave_m + h * 64 + (r & 63), g.M - 1);
+            const int ga = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), g.M - 1);
             const int gb = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), g.N - 1);
             S.src[h ? 3 : 0][p] = g.A + (size_t)ga * g.lda + kbeg + lc * 8;
             S.src[h ? 2 : 1][p] = g.B + (size_t)gb * g.ldb + kbeg + lc * 8;
@@ -251,25 +242,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
 
     bf16x8 a[8], b0[4], b1[4];
     for (int kt = 0; kt < S.nt; kt += 2) {
-        ktile<0, SHORT>(smem, S, kt, a_off, b_off, a, b0, b1, acc, nii);
-        if (kt + 1 < S.nt) ktile<1, SHORT>(smem, S, kt + 1, a_off, b_off, a, b0, b1, acc, nii);
+        ktile<0>(smem, S, kt, a_off, b_off, a, b0, b1, acc);
+        if (kt + 1 < S.nt) ktile<1>(smem, S, kt + 1, a_off, b_off, a, b0, b1, acc);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                   // re-align the two wave groups
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
-    // rows this wave may store: its own fragments only (short tiles: the next group's / the next tile's rows follow)
-    const int mw = wr * wave_m;
-    const int wave_rows = SHORT ? min((wr ? g.f1 : g.f0) * 16, g.tile_m - mw) : 128;
-    const int row_end = min(g.M, m0 + mw + wave_rows);
     // Epilogue: bf16 outputs without an extra input tile go through the bf16 LDS strip (full-line stores, half the LDS
     // bytes); the fp32-residual, GELU' and fp32 epilogues keep the fp32 staging shared with sc_gemm256.hip.
     if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) {
-        epilogue_bf16_lds<EPI>(acc, g, smem + wave * 4096, m0 + mw, n0 + wc * 64, lane, row_end);
+        epilogue_bf16_lds<EPI>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
     } else {
+        const int mw = wr * 128;
         float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
         EpiRegs<EPI> er;
-        sc_epi_load<EPI>(er, m0 + mw, n0 + wc * 64, lane, g, min(64, wave_rows));
+        sc_epi_load<EPI>(er, m0 + mw, n0 + wc * 64, lane, g, 64);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -278,23 +266,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
                 for (int j = 0; j < 4; ++j) sc_epi_put(ep, i, j, li, lg, acc[h * 4 + i][j]);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
-            sc_epilogue_store<EPI>(ep, er, m0 + mw + h * 64, n0 + wc * 64, lane, g, z, (h + 1 < 2) ? m0 + mw + 64 : -1,
-                                   min(64, max(wave_rows - h * 64, 0)));
+            sc_epilogue_store<EPI>(ep, er, m0 + mw + h * 64, n0 + wc * 64, lane, g, z, (h + 1 < 2) ? m0 + mw + 64 : -1, 64);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
-template <int EPI, bool SHORT = false>
+template <int EPI>
 int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<EPI, SHORT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
     }
-    gemm8p_kernel<EPI, SHORT><<<nblocks, 512, LDS_BYTES, st>>>(g);
+    gemm8p_kernel<EPI><<<nblocks, 512, LDS_BYTES, st>>>(g);
     SC_LAUNCH_CHECK();
     return 1;
 }
@@ -478,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void gemm8pp_kernel(const GemmArgs g, int t
             const int m0 = tm * BM, n0 = tn * BN;
             if (wr == 0) __builtin_amdgcn_s_barrier();           // waves 0-3 wait for 4-7: groups aligned
             __builtin_amdgcn_sched_barrier(0);
-            epilogue_bf16_lds<EPI>(acc, g, smem + RING + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane, g.M);
+            epilogue_bf16_lds<EPI>(acc, g, smem + RING + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -908,7 +895,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_f8_kernel(const GemmArgs g) {
         }
     }
     if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) {
-        epilogue_bf16_lds<EPI>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane, g.M);
+        epilogue_bf16_lds<EPI>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
     } else {
         const int mw = wr * 128;
         float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
@@ -985,37 +972,6 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     const int nblocks = g.ntm * g.ntn * splitk;
     if (mode == SC_GEMM_TN) {
         return launch_tn(g, nblocks, st);
-    }
-    // Short tiles (GemmArgs::f0 / f1 / tile_m): when the 256-row tiling leaves the last round mostly empty, tiles of F < 16
-    // row fragments can fill the rounds with proportionally less matrix work per tile.  Cost model per tile, in K-tile
-    // units: 1 (prologue) + ktiles * (0.15 + 0.85 F / 16) + 3 F / 16 (epilogue); SC_GEMM_TILE_F = 16 turns it off,
-    // 10..15 forces a height (tests / A-B runs), unset = choose by the model when it promises more than 5 %.
-    if (splitk == 1 && (epi == SC_EPI_BF16 || epi == SC_EPI_BF16_BIAS || epi == SC_EPI_F32_BIAS_RES)) {
-        const char* ef = getenv("SC_GEMM_TILE_F");
-        int F = 16;
-        const int forced = ef ? atoi(ef) : 0;
-        auto cost = [&](int f) {
-            const long long tiles = (long long)((g.M + 16 * f - 1) / (16 * f)) * g.ntn;
-            const double per = 1.0 + ktiles * (0.15 + 0.85 * f / 16.0) + 3.0 * f / 16.0;
-            return (double)((tiles + 255) / 256) * per;
-        };
-        if (forced >= 10 && forced <= 15) {
-            F = forced;
-        } else if (forced == 0 && g.M >= 4096 && (nblocks + 255) / 256 <= 6) {    // many rounds: the tail is a small share
-            double best = cost(16) * 0.95;
-            for (int f = 15; f >= 10; --f)
-                if (cost(f) < best) { best = cost(f); F = f; }
-        }
-        if (F < 16) {
-            g.f0 = (F + 1) / 2;
-            g.f1 = F - g.f0;
-            g.tile_m = 16 * F;
-            g.ntm = (g.M + g.tile_m - 1) / g.tile_m;
-            const int nb = g.ntm * g.ntn;
-            if (epi == SC_EPI_BF16) return launch<SC_EPI_BF16, true>(g, nb, st);
-            if (epi == SC_EPI_BF16_BIAS) return launch<SC_EPI_BF16_BIAS, true>(g, nb, st);
-            return launch<SC_EPI_F32_BIAS_RES, true>(g, nb, st);
-        }
     }
     // persistent walk of the tile list for the store-only bf16 epilogues once there is more than one round of tiles
     static const bool persist = !(getenv("SC_GEMM_PERSIST") && getenv("SC_GEMM_PERSIST")[0] == '0');

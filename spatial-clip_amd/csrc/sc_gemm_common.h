@@ -32,11 +32,6 @@ struct GemmArgs {
     float* colsum;        // TN + EPI_F32 only: [splitk][M] partial column sums of the At operand (bias gradient), or null
     const float* a_scale = nullptr;   // fp8 kernels only: per-row dequantisation factors of A [M] and B [N]
     const float* b_scale = nullptr;
-    // "Short" tiles of the NT kernel (sc_gemm8p.hip): a tile is F <= 16 MFMA row fragments tall instead of 16.  The two
-    // M-wave groups own f0 = ceil(F / 2) and f1 = F - f0 fragments; the tile stride is tile_m = 16 F rows.  Used when it
-    // turns a mostly empty last round of 256-row tiles into full rounds of shorter ones (e.g. 50 432 x 768: 591 tiles of
-    // 16 fragments = 2.31 -> 3 rounds, 729 tiles of 13 fragments = 2.85 -> 3 rounds of 0.81 of the matrix work each).
-    int f0 = 8, f1 = 8, tile_m = 256;
     int diag = 0;         // SC_EPI_DIAG (benchmark diagnostics only): 1 = GELU pair without its second store, 2 = without the GELU arithmetic
 };
 

@@ -186,57 +186,3 @@ def test_wgrad_with_fused_bias_grad(M, N, K, splitk):
     ops.gemm_wgrad_bias(dy.cuda(), x.cuda(), dw, db, M=M, N=N, K=K, splitk=splitk)
     torch.testing.assert_close(dw.cpu(), dy.float().t() @ x.float(), atol=2e-3 * max(1, K ** 0.5 / 8), rtol=2e-3)
     torch.testing.assert_close(db.cpu(), dy.float().sum(0), atol=2e-3 * max(1, K ** 0.5 / 8), rtol=1e-4)
-
-
-@pytest.mark.parametrize("F", [10, 11, 13, 14, 15])
-@pytest.mark.parametrize("K", [64, 192, 448])
-def test_nt_short_tiles_exact(F, K, monkeypatch):
-    """Short tiles of the NT kernel (SC_GEMM_TILE_F forces the height in 16-row fragments; production picks it from a cost
-    model when 256-row tiles leave the last round mostly empty): the two M-wave groups own ceil(F/2) / floor(F/2)
-    fragments, fragments beyond that are neither read nor multiplied, and each wave stores only its own rows.  Exact on
-    small integers for the three epilogues that have the variant; M ragged against every tile height, repeated."""
-    ops = _ops()
-    monkeypatch.setenv("SC_GEMM_TILE_F", str(F))
-    M, N = 197 * 5 + 3, 256 * 2 + 24
-    g = torch.Generator().manual_seed(F * 100 + K)
-    for rep in range(3):
-        a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
-        b = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
-        bias = torch.randint(-4, 5, (N,), generator=g).float()
-        res = torch.randint(-8, 9, (M, N), generator=g).float()
-        ref = a.float() @ b.float().t()
-        out = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device="cuda")        # one guard row behind the matrix
-        ops.gemm(ops.NT, ops.EPI_BF16, a.cuda(), b.cuda(), out, M=M, N=N, K=K)
-        assert torch.equal(out[:M].cpu(), ref.to(torch.bfloat16)), (F, K, rep)
-        assert bool((out[M] == 7.0).all())
-        ops.gemm(ops.NT, ops.EPI_BF16_BIAS, a.cuda(), b.cuda(), out, M=M, N=N, K=K, bias=bias.cuda())
-        assert torch.equal(out[:M].cpu(), (ref + bias).to(torch.bfloat16)), (F, K, rep, "bias")
-        o32 = torch.full((M + 1, N), 5.0, dtype=torch.float32, device="cuda")
-        ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, a.cuda(), b.cuda(), o32, M=M, N=N, K=K, bias=bias.cuda(), res=res.cuda())
-        assert torch.equal(o32[:M].cpu(), ref + bias + res), (F, K, rep, "residual")
-        assert bool((o32[M] == 5.0).all())
-
-
-def test_nt_short_tiles_are_chosen_for_the_tower_shapes_and_match_the_full_tiles(monkeypatch):
-    """ViT-B/16 at batch 256 (50 432 x 768: 591 full tiles = 2.31 rounds) and ViT-L/14 (65 792 x 1024: 1 028 = 4.02 rounds)
-    take short tiles by default; SC_GEMM_TILE_F=16 pins the 256-row tiling.  Same inputs, bit-identical outputs
-    (each output element is the same fp32 accumulation over K either way)."""
-    ops = _ops()
-    g = torch.Generator(device="cuda").manual_seed(1)
-    for M, N, K in ((256 * 197, 768, 768), (256 * 257, 1024, 1024)):
-        a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-        b = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
-        res = torch.randn(M, N, device="cuda", generator=g)
-        bias = torch.randn(N, device="cuda", generator=g)
-        outs = []
-        for f in ("16", None):
-            if f is None:
-                monkeypatch.delenv("SC_GEMM_TILE_F", raising=False)
-            else:
-                monkeypatch.setenv("SC_GEMM_TILE_F", f)
-            o = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-            ops.gemm(ops.NT, ops.EPI_BF16, a, b, o, M=M, N=N, K=K)
-            o32 = torch.empty((M, N), dtype=torch.float32, device="cuda")
-            ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, a, b, o32, M=M, N=N, K=K, bias=bias, res=res)
-            outs.append((o, o32))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
