@@ -61,6 +61,17 @@ int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long ld_src, int 
 int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
                 const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2, const float* bias,
                 const float* res, int ldres, const void* aux, int ldaux, void* stream);
+/* sc_gemm_fp8 with (a) a_scale_scalar != 0: a_scale_inv points at ONE factor for all rows of A8 (an operand quantised
+ * with a per-tensor scale) and (b) an optional e4m3 copy of the epilogue's bf16 output (SC_EPI_GELU_PAIR: h;
+ * SC_EPI_BF16_DGELU: dU) for the next GEMM: q8_out[M][ldq8] = e4m3(value * *q8_scale), and max|value| of the launch is
+ * max-reduced into q8_amax[64].  sc_fp8_scale_update turns the maxima of n tensors (amax_slots[n][64]) into next step's
+ * power-of-two scales (2^(floor(log2(448 / amax)) - margin_bits), left alone when nothing was recorded) and clears the
+ * slots: "delayed scaling" -- a tile cannot know its rows' maxima, the step before can. */
+int sc_gemm_fp8_q(int epi, const void* A8, int lda, const float* a_scale_inv, int a_scale_scalar, const void* B8, int ldb,
+                  const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2, const float* bias,
+                  const float* res, int ldres, const void* aux, int ldaux, void* q8_out, long long ldq8,
+                  const float* q8_scale, float* q8_amax, void* stream);
+int sc_fp8_scale_update(float* amax_slots, float* scale, float* scale_inv, int n, int margin_bits, void* stream);
 /* The quantiser fused into the kernels that hold a complete row (round 3): LayerNorm forward also emits the e4m3 copy
  * of its output (A operand of the qkv / c_fc forward GEMMs), LayerNorm backward the e4m3 copy of the new residual
  * gradient (A operand of the c_proj / out_proj data-gradient GEMMs; SC_EPI_BF16_DGELU takes aux = the pre-GELU tensor),

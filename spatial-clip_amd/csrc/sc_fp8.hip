@@ -73,7 +73,32 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const void* __restri
     }
 }
 
+// One thread per tensor: scale <- 2^(floor(log2(448 / amax)) - margin_bits) from the maximum the epilogues recorded during the
+// step that has just finished (left alone while nothing was recorded), then clear the 64 slots for the next step.
+__global__ void fp8_scale_update_kernel(float* __restrict__ amax_slots, float* __restrict__ scale,
+                                        float* __restrict__ scale_inv, int n, int margin_bits) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float amax = 0.f;
+    for (int k = 0; k < 64; ++k) {
+        amax = fmaxf(amax, amax_slots[t * 64 + k]);
+        amax_slots[t * 64 + k] = 0.f;
+    }
+    if (amax > 0.f && amax < 3.0e38f) {
+        const float s = exp2f(floorf(log2f(448.0f / amax)) - (float)margin_bits);
+        scale[t] = s;
+        scale_inv[t] = 1.0f / s;
+    }
+}
+
 }  // namespace
+
+extern "C" int sc_fp8_scale_update(float* amax_slots, float* scale, float* scale_inv, int n, int margin_bits, void* stream) {
+    SC_CHECK(n > 0 && amax_slots && scale && scale_inv && margin_bits >= 0 && margin_bits <= 8, "sc_fp8_scale_update: bad arguments");
+    fp8_scale_update_kernel<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(amax_slots, scale, scale_inv, n, margin_bits);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long ld_src, int rows, int cols, void* dst_fp8,
                                     long long ld_dst, float* scale_inv, float fixed_scale, void* stream) {
@@ -89,9 +114,10 @@ extern "C" int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long l
     return 0;
 }
 
-extern "C" int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
-                           const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
-                           const float* bias, const float* res, int ldres, const void* aux, int ldaux, void* stream) {
+static int gemm_fp8_impl(int epi, const void* A8, int lda, const float* a_scale_inv, int a_scale_scalar, const void* B8, int ldb,
+                         const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
+                         const float* bias, const float* res, int ldres, const void* aux, int ldaux, void* q8_out,
+                         long long ldq8, const float* q8_scale, float* q8_amax, void* stream) {
     SC_CHECK(M > 0 && N > 0 && K > 0 && (K % 128) == 0, "sc_gemm_fp8: K (%d) must be a positive multiple of 128", K);
     SC_CHECK((lda % 16) == 0 && (ldb % 16) == 0 && ((uintptr_t)A8 % 16) == 0 && ((uintptr_t)B8 % 16) == 0,
              "sc_gemm_fp8: operand rows must be 16-byte aligned (lda=%d ldb=%d)", lda, ldb);
@@ -102,8 +128,29 @@ extern "C" int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scal
     g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
     g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
     g.aux = (const bf16*)aux; g.ldaux = ldaux; g.colsum = nullptr; g.tile_offset = 0;
-    g.a_scale = a_scale_inv; g.b_scale = b_scale_inv;
+    g.a_scale = a_scale_inv; g.b_scale = b_scale_inv; g.a_scale_scalar = a_scale_scalar;
+    if (q8_out != nullptr) {
+        SC_CHECK(epi == SC_EPI_GELU_PAIR || epi == SC_EPI_BF16_DGELU, "sc_gemm_fp8_q: the e4m3 second output exists for the GELU pair / GELU' epilogues");
+        SC_CHECK(q8_scale != nullptr && q8_amax != nullptr && ldq8 >= N && (ldq8 % 8) == 0 && ((uintptr_t)q8_out % 8) == 0,
+                 "sc_gemm_fp8_q: q8 output needs its scale, 64 amax slots and an 8-byte aligned row stride (ldq8=%lld)", ldq8);
+        g.q8 = (unsigned char*)q8_out; g.ldq8 = ldq8; g.q8_scale = q8_scale; g.q8_amax = q8_amax;
+    }
     const int took = sc_gemm8p_fp8(epi, g, (hipStream_t)stream);
     SC_CHECK(took == 1, "sc_gemm_fp8: shape not supported (M=%d N=%d K=%d epi=%d)", M, N, K, epi);
     return 0;
+}
+
+extern "C" int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
+                           const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
+                           const float* bias, const float* res, int ldres, const void* aux, int ldaux, void* stream) {
+    return gemm_fp8_impl(epi, A8, lda, a_scale_inv, 0, B8, ldb, b_scale_inv, M, N, K, C, ldc, C2, ldc2, bias, res, ldres, aux,
+                         ldaux, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int sc_gemm_fp8_q(int epi, const void* A8, int lda, const float* a_scale_inv, int a_scale_scalar, const void* B8,
+                             int ldb, const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
+                             const float* bias, const float* res, int ldres, const void* aux, int ldaux, void* q8_out,
+                             long long ldq8, const float* q8_scale, float* q8_amax, void* stream) {
+    return gemm_fp8_impl(epi, A8, lda, a_scale_inv, a_scale_scalar, B8, ldb, b_scale_inv, M, N, K, C, ldc, C2, ldc2, bias, res,
+                         ldres, aux, ldaux, q8_out, ldq8, q8_scale, q8_amax, stream);
 }

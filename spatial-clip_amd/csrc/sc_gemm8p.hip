@@ -44,8 +44,10 @@ SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
 // are packed to bf16 BEFORE the LDS trip (half the LDS bytes of the fp32 staging in sc_gemm_common.h), 16-B chunks
 // XOR-swizzled by row so the 8-B writes (2-way at worst) and 16-B reads spread over the banks.
 //   BF16 / BF16_BIAS: C = bf16(acc (+ bias));  GELU_PAIR: C = u = bf16(acc + bias), C2 = bf16(gelu(float(u))).
-template <int EPI>
+template <int EPI, bool Q8 = false>
 SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* strip, int row0, int col0, int lane) {
+    float amax_lane = 0.f;
+    const float q8s = (Q8 && EPI == SC_EPI_GELU_PAIR && g.q8) ? *g.q8_scale : 0.f;
     const int li = lane & 15, lg = lane >> 4;
     constexpr bool kBias = (EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR);
     f32x4 bj[4];
@@ -92,12 +94,19 @@ SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* st
                     }
                     if (g.diag & 1) asm volatile("" ::"v"(o));
                     else *reinterpret_cast<bf16x8*>(C2 + (size_t)grow * g.ldc2 + gcol) = o;
+                    if (Q8 && g.q8) {                    // e4m3 copy of h for the c_proj forward GEMM (GemmArgs::q8)
+                        float r[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { r[e] = (float)o[e]; amax_lane = fmaxf(amax_lane, fabsf(r[e])); }
+                        *reinterpret_cast<u32x2*>(g.q8 + (size_t)grow * g.ldq8 + gcol) = sc_pack8_fp8(r, q8s);
+                    }
                 }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
+    if (Q8 && EPI == SC_EPI_GELU_PAIR && g.q8) sc_amax_publish(amax_lane, g.q8_amax);
 }
 
 // ring slot of half-tile q (0: A half 0, 1: B half 0, 2: B half 1, 3: A half 1) of the K tile with parity D
@@ -889,17 +898,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_f8_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float sa = g.a_scale ? g.a_scale[min(mrow + i * 16, g.M - 1)] : 1.0f;
+            const float sa = g.a_scale ? g.a_scale[g.a_scale_scalar ? 0 : min(mrow + i * 16, g.M - 1)] : 1.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] *= sb[j] * sa;
         }
     }
     if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) {
-        epilogue_bf16_lds<EPI>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
+        epilogue_bf16_lds<EPI, true>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
     } else {
         const int mw = wr * 128;
         float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
         EpiRegs<EPI> er;
+        float amax_lane = 0.f;
         sc_epi_load<EPI>(er, m0 + mw, n0 + wc * 64, lane, g, 64);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -909,10 +919,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_f8_kernel(const GemmArgs g) {
                 for (int j = 0; j < 4; ++j) sc_epi_put(ep, i, j, li, lg, acc[h * 4 + i][j]);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
-            sc_epilogue_store<EPI>(ep, er, m0 + mw + h * 64, n0 + wc * 64, lane, g, 0, (h + 1 < 2) ? m0 + mw + 64 : -1, 64);
+            sc_epilogue_store<EPI, true>(ep, er, m0 + mw + h * 64, n0 + wc * 64, lane, g, 0, (h + 1 < 2) ? m0 + mw + 64 : -1,
+                                         64, 0, &amax_lane);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
         }
+        if (EPI == SC_EPI_BF16_DGELU && g.q8) sc_amax_publish(amax_lane, g.q8_amax);
     }
 }
 

@@ -32,6 +32,16 @@ struct GemmArgs {
     float* colsum;        // TN + EPI_F32 only: [splitk][M] partial column sums of the At operand (bias gradient), or null
     const float* a_scale = nullptr;   // fp8 kernels only: per-row dequantisation factors of A [M] and B [N]
     const float* b_scale = nullptr;
+    // fp8 kernels only -- e4m3 copy of the epilogue's bf16 output for the NEXT GEMM (GELU pair: h, A operand of c_proj;
+    // GELU': dU, A operand of the c_fc data gradient) with ONE scale for the whole tensor, taken from the previous step's
+    // maximum ("delayed scaling": a tile cannot know its rows' maxima, sc_fp8.hip): q8 = e4m3(value * *q8_scale), and the
+    // maximum of |value| over the launch is max-reduced into q8_amax[64] (slot = workgroup & 63; non-negative floats
+    // compared as integers) for sc_fp8_scale_update.  a_scale_scalar: a_scale points at ONE factor, not at M of them.
+    unsigned char* q8 = nullptr;
+    long long ldq8 = 0;
+    const float* q8_scale = nullptr;
+    float* q8_amax = nullptr;
+    int a_scale_scalar = 0;
     int diag = 0;         // SC_EPI_DIAG (benchmark diagnostics only): 1 = GELU pair without its second store, 2 = without the GELU arithmetic
 };
 
@@ -63,6 +73,26 @@ SC_DEVICE float sc_gelu_grad_fast(float x) {
     sc_gelu_qe(x, q, e);
     const float step = x >= 0.0f ? 1.0f : 0.0f;
     return __builtin_fmaf(e, __builtin_fmaf(x, 0.3989422804014327f, -copysignf(q, x)), step);
+}
+
+// eight values -> eight e4m3 bytes (value * s, saturating at +-448)
+SC_DEVICE u32x2 sc_pack8_fp8(const float (&v)[8], float s) {
+    float c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = fminf(fmaxf(v[k] * s, -448.f), 448.f);
+    int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w0, true);
+    int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], w1, true);
+    return (u32x2){(unsigned)w0, (unsigned)w1};
+}
+// launch-wide maximum of non-negative floats: one atomic per wave into one of 64 slots
+SC_DEVICE void sc_amax_publish(float amax_lane, float* slots) {
+    float a = amax_lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a = fmaxf(a, __shfl_xor(a, off, 64));
+    if ((threadIdx.x & 63) == 0 && a > 0.f)
+        atomicMax(reinterpret_cast<unsigned*>(slots) + (blockIdx.x & 63), __float_as_uint(a));
 }
 
 // Stage one MFMA accumulator block (swapped orientation: lane owns C[m = li][n = 4*lg .. +3]) into the wave's LDS tile
@@ -104,9 +134,9 @@ SC_DEVICE void sc_epi_load(EpiRegs<EPI>& e, int gm0, int gn0, int lane, const Ge
 // Drain a wave-private 64x64 fp32 tile (row stride SC_EPI_LD) to global memory with full-row-segment accesses.
 // If next_gm0 >= 0 the input registers are refilled for the sub-tile at (next_gm0, gn0) as they are consumed.
 // hi_col_skip: the tile's columns 32..63 sit that many columns further right in C (two 32-column blocks; fp32 only).
-template <int EPI>
+template <int EPI, bool Q8 = false>
 SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int gn0, int lane, const GemmArgs& g, int z,
-                                 int next_gm0 = -1, int mrows = 64, int hi_col_skip = 0) {
+                                 int next_gm0 = -1, int mrows = 64, int hi_col_skip = 0, float* amax_lane = nullptr) {
     const int mlim = min(g.M, gm0 + mrows);
     if (EPI == SC_EPI_F32 || EPI == SC_EPI_F32_BIAS_RES) {
         float* C = reinterpret_cast<float*>(g.C) + (size_t)z * g.slab_stride;
@@ -166,6 +196,12 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
                 *reinterpret_cast<bf16x8*>(C + (size_t)gm * g.ldc + gn) = o;
+                if (Q8 && EPI == SC_EPI_BF16_DGELU && g.q8) {          // e4m3 copy of dU for the c_fc data-gradient GEMM
+                    float r[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { r[k] = (float)o[k]; *amax_lane = fmaxf(*amax_lane, fabsf(r[k])); }
+                    *reinterpret_cast<u32x2*>(g.q8 + (size_t)gm * g.ldq8 + gn) = sc_pack8_fp8(r, *g.q8_scale);
+                }
                 if (EPI == SC_EPI_GELU_PAIR) {
                     bf16x8 h;
 #pragma unroll

@@ -480,10 +480,21 @@ def quantize_rows_fp8(src: torch.Tensor, dst: Optional[torch.Tensor] = None, sca
     return dst, scale_inv
 
 
+def fp8_scale_update(amax_slots: torch.Tensor, scale: torch.Tensor, scale_inv: torch.Tensor, margin_bits: int = 1) -> None:
+    """Delayed scaling: next step's per-tensor e4m3 scales from the maxima the epilogues recorded ([n, 64] slots, cleared)."""
+    _req(amax_slots, torch.float32, "amax_slots"); _req(scale, torch.float32, "scale"); _req(scale_inv, torch.float32, "scale_inv")
+    n = scale.numel()
+    if amax_slots.numel() != n * 64 or scale_inv.numel() != n:
+        raise ValueError("fp8_scale_update: amax_slots must be [n, 64] for n scales")
+    check(_lib.lib().sc_fp8_scale_update(amax_slots.data_ptr(), scale.data_ptr(), scale_inv.data_ptr(), n, int(margin_bits),
+                                         _stream()), "sc_fp8_scale_update")
+
+
 def gemm_fp8(epi: int, a8: torch.Tensor, a_scale_inv: torch.Tensor, b8: torch.Tensor, b_scale_inv: torch.Tensor,
              out: torch.Tensor, *, M: int, N: int, K: int, out2: Optional[torch.Tensor] = None,
              bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
-             aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+             aux: Optional[torch.Tensor] = None, a_scale_scalar: bool = False, q8_out: Optional[torch.Tensor] = None,
+             q8_scale: Optional[torch.Tensor] = None, q8_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C[M,N] = dequant(A8[M,K] . B8[N,K]^T) with the bf16 GEMM's epilogues (see sc_gemm_fp8); ``aux`` = the pre-GELU
     tensor of EPI_BF16_DGELU (the c_proj data-gradient GEMM)."""
     for t_, n in ((a8, "a8"), (b8, "b8")):
@@ -496,11 +507,14 @@ def gemm_fp8(epi: int, a8: torch.Tensor, a_scale_inv: torch.Tensor, b8: torch.Te
     if KERNEL_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    rc = _lib.lib().sc_gemm_fp8(epi, a8.data_ptr(), a8.stride(0), a_scale_inv.data_ptr(), b8.data_ptr(), b8.stride(0),
-                                b_scale_inv.data_ptr(), M, N, K, out.data_ptr(), out.stride(0), _ptr(out2),
-                                out2.stride(0) if out2 is not None else 0, _ptr(bias), _ptr(res),
-                                res.stride(0) if res is not None else 0, _ptr(aux),
-                                aux.stride(0) if aux is not None else 0, _stream())
+    if q8_out is not None and (q8_out.dtype != torch.uint8 or not q8_out.is_cuda or q8_out.stride(-1) != 1):
+        raise TypeError("gemm_fp8: q8_out must be a device uint8 matrix")
+    rc = _lib.lib().sc_gemm_fp8_q(epi, a8.data_ptr(), a8.stride(0), a_scale_inv.data_ptr(), int(a_scale_scalar),
+                                  b8.data_ptr(), b8.stride(0), b_scale_inv.data_ptr(), M, N, K, out.data_ptr(),
+                                  out.stride(0), _ptr(out2), out2.stride(0) if out2 is not None else 0, _ptr(bias),
+                                  _ptr(res), res.stride(0) if res is not None else 0, _ptr(aux),
+                                  aux.stride(0) if aux is not None else 0, _ptr(q8_out),
+                                  q8_out.stride(0) if q8_out is not None else 0, _ptr(q8_scale), _ptr(q8_amax), _stream())
     if ev is not None:
         ev[1].record()
         KERNEL_EVENTS.append(("gemm_nt_fp8", 2.0 * M * N * K, ev))

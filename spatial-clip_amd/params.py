@@ -242,11 +242,15 @@ class ParamStore:
                 # e4m3 operands exist only where the quantiser of the OTHER operand is fused into the kernel that
                 # produces it (towers.TransformerStack): forward qkv / c_fc (A = LayerNorm output), data gradients of
                 # c_proj / out_proj (A = the residual gradient LayerNorm backward emits; B = the transposed weight)
-                for leaf, n_out, k_in in (("attn.in_proj_weight", 3 * dd, dd), ("mlp.c_fc.weight", mlp, dd)):
+                # c_proj forward / c_fc data gradient: A = the e4m3 copy the GELU / GELU' epilogues emit with the previous
+                # step's per-tensor scale (delayed scaling, sc_fp8_scale_update)
+                for leaf, n_out, k_in in (("attn.in_proj_weight", 3 * dd, dd), ("mlp.c_fc.weight", mlp, dd),
+                                          ("mlp.c_proj.weight", dd, mlp)):
                     c = self.copies[prefix + leaf]
                     c.w8 = torch.zeros((n_out, k_in), dtype=torch.uint8, device=self.device)
                     c.w8s = torch.ones(n_out, dtype=torch.float32, device=self.device)
-                for leaf, n_out, k_in in (("attn.out_proj.weight", dd, dd), ("mlp.c_proj.weight", dd, mlp)):
+                for leaf, n_out, k_in in (("attn.out_proj.weight", dd, dd), ("mlp.c_proj.weight", dd, mlp),
+                                          ("mlp.c_fc.weight", mlp, dd)):
                     c = self.copies[prefix + leaf]
                     c.wb8 = torch.zeros((k_in, n_out), dtype=torch.uint8, device=self.device)
                     c.wb8s = torch.ones(k_in, dtype=torch.float32, device=self.device)

@@ -68,6 +68,14 @@ class TransformerStack:
         # kept for the backward (12 of the 36 d bytes a token saves per block); the backward rebuilds them, bit-identically,
         # from the saved residual stream / pre-activation right before the weight-gradient GEMMs that read them
         self.recompute = False
+        # fp8 delayed scaling (h = GELU output -> c_proj forward, dU -> c_fc data gradient): per-tensor scales of the
+        # previous step; tensor 2 i = h of block i, 2 i + 1 = dU of block i.  Not "ready" until one backward has run.
+        self._dq_ready = False
+        if self.fp8:
+            n = 2 * layers
+            self._dq_scale = torch.zeros(n, dtype=F32, device=store.device)
+            self._dq_scale_inv = torch.ones(n, dtype=F32, device=store.device)
+            self._dq_amax = torch.zeros((n, 64), dtype=F32, device=store.device)
 
     def set_grad_checkpointing(self, enable: bool = True) -> None:
         self.recompute = bool(enable)
@@ -137,11 +145,20 @@ class TransformerStack:
                               q8=qa and qa[0], q8_scale_inv=qa and qa[1])
             u = bf.get(f"u.{i}", (M, mlp), BF16)
             h = self._act("h", i, (M, mlp))
+            hq = None
+            if self.fp8:                      # the GELU epilogue also emits e4m3(h) with last step's scale + records max|h|
+                h8 = bf.get("q8.h", (M, mlp), torch.uint8)
+                hq = dict(q8_out=h8, q8_scale=self._dq_scale[2 * i:2 * i + 1], q8_amax=self._dq_amax[2 * i])
             self._linear_fwd(ops.EPI_GELU_PAIR, a2, self._n(i, "mlp.c_fc.weight"), u,
-                             M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h, q8=qa)
+                             M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h, q8=qa, **(hq or {}))
             xo = bf.get(f"xout.{i}", (M, d), F32)
-            self._linear_fwd(ops.EPI_F32_BIAS_RES, h, self._n(i, "mlp.c_proj.weight"), xo,
-                             M=M, N=d, K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
+            cpj = s.copies[self._n(i, "mlp.c_proj.weight")]
+            if self.fp8 and self._dq_ready and cpj.w8 is not None:
+                ops.gemm_fp8(ops.EPI_F32_BIAS_RES, h8, self._dq_scale_inv[2 * i:2 * i + 1], cpj.w8, cpj.w8s, xo, M=M, N=d,
+                             K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid, a_scale_scalar=True)
+            else:
+                self._linear_fwd(ops.EPI_F32_BIAS_RES, h, self._n(i, "mlp.c_proj.weight"), xo,
+                                 M=M, N=d, K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
             x = xo
         return x
 
@@ -292,8 +309,9 @@ class TransformerStack:
             """Data-gradient GEMM out[M, N] = g[M, K] . W (NT against the transposed weight copy): e4m3 operands when the
             residual gradient's e4m3 copy is live in ``qg`` and the weight has one, bf16 otherwise."""
             c = cp_of(name)
+            q8kw = kw.pop("q8kw", None)
             if have_q8 and qg is not None and c.wb8 is not None:
-                ops.gemm_fp8(epi, qg[0], qg[1], c.wb8, c.wb8s, out, M=M, N=N, K=K, **kw)
+                ops.gemm_fp8(epi, qg[0], qg[1], c.wb8, c.wb8s, out, M=M, N=N, K=K, **kw, **(q8kw or {}))
             else:
                 ops.gemm(ops.NT, epi, g_bf, c.wb, out, M=M, N=N, K=K, **kw)
 
@@ -324,7 +342,12 @@ class TransformerStack:
                 ops.colsum_bf16(g0, M, d, g("mlp.c_proj.bias"))
             # ---- MLP branch: x_out = xmid + c_proj(gelu(c_fc(ln_2(xmid))))
             before_write(dU)
-            dgrad(ops.EPI_BF16_DGELU, g0, self._n(i, "mlp.c_proj.weight"), dU, N=mlp, K=d, have_q8=g_has_q8, aux=u)
+            dq = None
+            if self.fp8:                      # GELU' epilogue: e4m3(dU) with last step's scale + max|dU| for the next one
+                dU8 = bf.get("q8.dU", (M, mlp), torch.uint8)
+                dq = dict(q8_out=dU8, q8_scale=self._dq_scale[2 * i + 1:2 * i + 2], q8_amax=self._dq_amax[2 * i + 1])
+            dU_has_q8 = bool(dq) and g_has_q8 and self._dq_ready
+            dgrad(ops.EPI_BF16_DGELU, g0, self._n(i, "mlp.c_proj.weight"), dU, N=mlp, K=d, have_q8=g_has_q8, aux=u, q8kw=dq)
 
             def w_mlp(g0=g0, h=h, dU=dU, a2=a2, g=g):
                 ops.gemm(ops.TN, ops.EPI_F32, g0, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M, splitk=_splitk_for(d, mlp, M))
@@ -337,7 +360,12 @@ class TransformerStack:
                 ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
                                   bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32), M, d)
             on_side(w_mlp, (g0, dU, h, a2) if self.recompute else (g0, dU))
-            ops.gemm(ops.NT, ops.EPI_BF16, dU, cp("mlp.c_fc.weight").wb, dA, M=M, N=d, K=mlp)
+            cfc = cp("mlp.c_fc.weight")
+            if dU_has_q8 and cfc.wb8 is not None:
+                ops.gemm_fp8(ops.EPI_BF16, dU8, self._dq_scale_inv[2 * i + 1:2 * i + 2], cfc.wb8, cfc.wb8s, dA, M=M, N=d, K=mlp,
+                             a_scale_scalar=True)
+            else:
+                ops.gemm(ops.NT, ops.EPI_BF16, dU, cfc.wb, dA, M=M, N=d, K=mlp)
             # LN2 backward accumulates into the residual gradient; its column sum is out_proj.bias' gradient
             rpos = (rpos + 1) % 3
             g1 = ring[rpos]
@@ -369,6 +397,9 @@ class TransformerStack:
             g_has_q8 = qg is not None
             if on_layer_done is not None:
                 on_side(lambda i=i: on_layer_done(i), ())     # the bucket all-reduce follows the side stream
+        if self.fp8:                          # next step's per-tensor scales from this step's recorded maxima
+            ops.fp8_scale_update(self._dq_amax, self._dq_scale, self._dq_scale_inv, margin_bits=1)
+            self._dq_ready = True
         if overlap:
             ev = torch.cuda.Event()
             ev.record(side)

@@ -250,3 +250,50 @@ def test_gemm_fp8_dgelu_epilogue_exact_inputs():
     torch.nn.functional.gelu(x).sum().backward()
     ref = ((a.double() @ b.double().t()).float() * x.grad)
     torch.testing.assert_close(o8.float().cpu(), ref.to(torch.bfloat16).float(), atol=3e-2, rtol=3e-2)
+
+
+def test_delayed_scaling_outputs_of_the_gelu_epilogues():
+    """sc_gemm_fp8_q: the GELU-pair / GELU' epilogues also emit the e4m3 copy of their bf16 output with a per-tensor scale
+    and record max|value| in 64 slots; sc_fp8_scale_update turns the maximum into next step's power-of-two scale (one
+    margin bit) and clears the slots; a consumer GEMM takes the copy with a scalar a_scale."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 197 * 3 + 7, 1024, 256
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g) * K ** -0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    a8, sa = ops.quantize_rows_fp8(a.cuda())
+    b8, sb = ops.quantize_rows_fp8(b.cuda())
+    u = torch.empty((M, N), dtype=torch.bfloat16, device="cuda"); h = torch.empty_like(u)
+    h8 = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+    scale = torch.full((2,), 16.0, device="cuda"); scale_inv = 1.0 / scale
+    amax = torch.zeros((2, 64), device="cuda")
+    ops.gemm_fp8(ops.EPI_GELU_PAIR, a8, sa, b8, sb, u, M=M, N=N, K=K, bias=bias.cuda(), out2=h,
+                 q8_out=h8, q8_scale=scale[0:1], q8_amax=amax[0])
+    hf = h.float()
+    assert float(amax[0].max()) == float(hf.abs().max())
+    want = (hf * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(h8, want)
+    aux = torch.randn(M, N, generator=g).bfloat16().cuda()
+    du = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    du8 = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+    ops.gemm_fp8(ops.EPI_BF16_DGELU, a8, sa, b8, sb, du, M=M, N=N, K=K, aux=aux, q8_out=du8, q8_scale=scale[1:2], q8_amax=amax[1])
+    assert float(amax[1].max()) == float(du.float().abs().max())
+    assert torch.equal(du8, (du.float() * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+    m0, m1 = float(amax[0].max()), float(amax[1].max())
+    ops.fp8_scale_update(amax, scale, scale_inv, margin_bits=1)
+    import math
+    assert float(scale[0]) == 2.0 ** (math.floor(math.log2(448.0 / m0)) - 1) and float(scale_inv[0]) == 1.0 / float(scale[0])
+    assert float(scale[1]) == 2.0 ** (math.floor(math.log2(448.0 / m1)) - 1)
+    assert float(amax.abs().max()) == 0.0
+    ops.fp8_scale_update(amax, scale, scale_inv, margin_bits=1)          # nothing recorded: scales stay
+    assert float(scale[0]) == 2.0 ** (math.floor(math.log2(448.0 / m0)) - 1)
+    # consumer: A = h8 with the scalar factor 1 / 16 (the scale it was written with)
+    w = torch.randn(256, N, generator=g) * N ** -0.5
+    w8, sw = ops.quantize_rows_fp8(w.cuda())
+    out = torch.empty((M, 256), device="cuda")
+    ops.gemm_fp8(ops.EPI_F32, h8, torch.full((1,), 1.0 / 16.0, device="cuda"), w8, sw, out, M=M, N=256, K=N, a_scale_scalar=True)
+    exact = (h8.view(torch.float8_e4m3fn).float().double() / 16.0) @ deq(w8, sw).double().t()
+    assert float((out.double() - exact).abs().max() / exact.abs().max()) < 1e-3
+    full = hf.double() @ w.cuda().double().t()
+    assert float((out.double() - full).norm() / full.norm()) < 0.05

@@ -176,6 +176,20 @@ def test_configs4_vitl14_gene_transformer_full_depth_vs_fp32_oracle(precision):
     assert cfg.vision.layers == 24 and cfg.vision.width == 1024 and cfg.vision.patch_size == 14 and cfg.vision.tokens == 257
     assert cfg.gene.kind == "transformer" and cfg.gene.layers == 6 and cfg.embed_dim == 768
     batch = data.synthetic_batch(B, 224, 20000, K=8)
+    if precision == "fp8":
+        # The e4m3 copies of h / dU use the PREVIOUS step's per-tensor scales (delayed scaling): prime them with one full
+        # training step.  The schedule's first step runs at lr = 0, so the weights under test stay the initial ones.
+        before = {k: t.clone() for k, t in n.state_dict().items()}
+        oc = m.configure_optimizers()
+        db = {k: v.cuda() for k, v in batch.items()}
+        loss = m.training_step(db, 0)
+        loss.backward()
+        oc["optimizer"].step(grad_scale=1.0, max_norm=1.0)
+        oc["lr_scheduler"]["scheduler"].step()
+        assert all(torch.equal(before[k], t) for k, t in n.state_dict().items())
+        st = n.vision.stack            # (the class-token-only last block has no full-width GELU GEMMs: its two entries stay 0)
+        assert st._dq_ready and float(st._dq_scale[:2 * (st.layers - 1)].min()) > 0.0
+        del loss, oc
     with torch.no_grad():
         out = m.model_step({k: v.cuda() for k, v in batch.items()})
         torch.cuda.synchronize()
