@@ -71,6 +71,7 @@ class TransformerStack:
         # fp8 delayed scaling (h = GELU output -> c_proj forward, dU -> c_fc data gradient): per-tensor scales of the
         # previous step; tensor 2 i = h of block i, 2 i + 1 = dU of block i.  Not "ready" until one backward has run.
         self._dq_ready = False
+        self._dq_on = os.environ.get("SC_FP8_DELAYED", "1") != "0"      # A/B switch: 0 keeps h / dU consumers in bf16
         if self.fp8:
             n = 2 * layers
             self._dq_scale = torch.zeros(n, dtype=F32, device=store.device)
@@ -146,14 +147,14 @@ class TransformerStack:
             u = bf.get(f"u.{i}", (M, mlp), BF16)
             h = self._act("h", i, (M, mlp))
             hq = None
-            if self.fp8:                      # the GELU epilogue also emits e4m3(h) with last step's scale + records max|h|
+            if self.fp8 and self._dq_on:      # the GELU epilogue also emits e4m3(h) with last step's scale + records max|h|
                 h8 = bf.get("q8.h", (M, mlp), torch.uint8)
                 hq = dict(q8_out=h8, q8_scale=self._dq_scale[2 * i:2 * i + 1], q8_amax=self._dq_amax[2 * i])
             self._linear_fwd(ops.EPI_GELU_PAIR, a2, self._n(i, "mlp.c_fc.weight"), u,
                              M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h, q8=qa, **(hq or {}))
             xo = bf.get(f"xout.{i}", (M, d), F32)
             cpj = s.copies[self._n(i, "mlp.c_proj.weight")]
-            if self.fp8 and self._dq_ready and cpj.w8 is not None:
+            if hq is not None and self._dq_ready and cpj.w8 is not None:
                 ops.gemm_fp8(ops.EPI_F32_BIAS_RES, h8, self._dq_scale_inv[2 * i:2 * i + 1], cpj.w8, cpj.w8s, xo, M=M, N=d,
                              K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid, a_scale_scalar=True)
             else:
@@ -343,7 +344,7 @@ class TransformerStack:
             # ---- MLP branch: x_out = xmid + c_proj(gelu(c_fc(ln_2(xmid))))
             before_write(dU)
             dq = None
-            if self.fp8:                      # GELU' epilogue: e4m3(dU) with last step's scale + max|dU| for the next one
+            if self.fp8 and self._dq_on:      # GELU' epilogue: e4m3(dU) with last step's scale + max|dU| for the next one
                 dU8 = bf.get("q8.dU", (M, mlp), torch.uint8)
                 dq = dict(q8_out=dU8, q8_scale=self._dq_scale[2 * i + 1:2 * i + 2], q8_amax=self._dq_amax[2 * i + 1])
             dU_has_q8 = bool(dq) and g_has_q8 and self._dq_ready
@@ -397,7 +398,7 @@ class TransformerStack:
             g_has_q8 = qg is not None
             if on_layer_done is not None:
                 on_side(lambda i=i: on_layer_done(i), ())     # the bucket all-reduce follows the side stream
-        if self.fp8:                          # next step's per-tensor scales from this step's recorded maxima
+        if self.fp8 and self._dq_on:          # next step's per-tensor scales from this step's recorded maxima
             ops.fp8_scale_update(self._dq_amax, self._dq_scale, self._dq_scale_inv, margin_bits=1)
             self._dq_ready = True
         if overlap:

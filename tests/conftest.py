@@ -17,3 +17,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory_between_tests():
+    """A net owns tens (configs[4] at 1024 pairs: ~177) of GiB of device buffers through reference cycles (parameters <->
+    parameter store, autograd node <-> net): they are freed only by a cycle collection, which Python schedules by host
+    allocation counts, not by device memory.  Collect after every test so that the next large model finds the HBM free."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    except Exception:
+        pass
