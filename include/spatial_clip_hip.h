@@ -239,6 +239,15 @@ int sc_exp_scalar_bwd(const float* y, const float* dy, float* dx, float mult, vo
  * params12[B][12] = {x0, y0, crop_w, crop_h, brightness, contrast, saturation, order, flip, 0, 0, 0}; mean3 / std3 are
  * HOST pointers (configs/model/spatial_clip.yaml:12-17, src/open_clip/constants.py:1-2). */
 int sc_knn_alpha(const float* xy, int N, int K, int mode, float sigma, int* nbr_index, float* alpha, void* stream);
+/* sc_png_decode: B PNG files as they sit in the shards (8-bit RGB / RGBA, not interlaced; concatenated in `files`, file b =
+ * bytes [offsets[b], offsets[b+1]), all DEVICE memory) -> uint8 tiles out_rgb[B][H][W][3], one wave per tile: zlib inflate
+ * (dynamic / fixed / stored blocks, IDAT chunks joined) and the five scanline filters on the device -- what
+ * PIL.Image.open(...).convert("RGB") does on the reference's dataloader workers.  status[b] = 0, or an error code (wrong size,
+ * unsupported colour type, damaged stream, ...): the caller decodes those tiles on the host.  scratch:
+ * sc_png_decode_scratch_bytes(B, H, W) bytes. */
+long long sc_png_decode_scratch_bytes(int B, int H, int W);
+int sc_png_decode(const void* files, const long long* offsets, int B, void* out_rgb, int H, int W, void* scratch, int* status,
+                  void* stream);
 int sc_augment_tiles(const void* src_u8_hwc, int B, int H, int W, const float* params12, float* out_nchw, int S,
                      const float* mean3_host, const float* std3_host, void* stream);
 

@@ -445,6 +445,23 @@ def knn_alpha(xy: torch.Tensor, K: int, mode: str = "inverse", sigma: float = 1.
     return nbr, alpha
 
 
+def png_decode(files: torch.Tensor, offsets: torch.Tensor, H: int, W: int):
+    """Concatenated PNG files (device uint8 [total]) + int64 offsets [B + 1] -> (uint8 [B, H, W, 3], int32 status [B])."""
+    if not files.is_cuda or files.dtype != torch.uint8 or files.dim() != 1 or not files.is_contiguous():
+        raise TypeError("png_decode: files must be a contiguous device uint8 vector")
+    _req(offsets, torch.int64, "offsets")
+    B = offsets.numel() - 1
+    if B < 1:
+        raise ValueError("png_decode: offsets must hold B + 1 entries")
+    l = _lib.lib()
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=files.device)
+    status = torch.full((B,), -1, dtype=torch.int32, device=files.device)
+    scratch = workspace(l.sc_png_decode_scratch_bytes(B, H, W), files.device, "png", torch.uint8)
+    check(l.sc_png_decode(files.data_ptr(), offsets.data_ptr(), B, out.data_ptr(), H, W, scratch.data_ptr(),
+                          status.data_ptr(), _stream()), "sc_png_decode")
+    return out, status
+
+
 def augment_tiles(src_u8: torch.Tensor, params: torch.Tensor, out_size: int, mean, std) -> torch.Tensor:
     """uint8 [B,H,W,3] + params fp32 [B,12] -> normalised fp32 [B,3,S,S] (crop, resize, colour jitter, normalise)."""
     if not src_u8.is_cuda or src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[3] != 3 \

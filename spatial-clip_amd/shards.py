@@ -98,6 +98,22 @@ def decode_png(png: bytes, size: Optional[int] = None) -> np.ndarray:
     return np.asarray(im, dtype=np.uint8)
 
 
+def decode_png_batch(pngs: Sequence[bytes], size: int, device=None) -> torch.Tensor:
+    """PNG files -> device uint8 [B, size, size, 3].  The compressed bytes go to the GPU as they are and ``sc_png_decode``
+    inflates / unfilters them there (one wave per tile); tiles it declines (status != 0: another size, palette / gray /
+    16-bit / interlaced files, a damaged stream) are decoded by PIL on the host and patched in."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    lens = np.fromiter((len(p) for p in pngs), dtype=np.int64, count=len(pngs))
+    offsets = np.zeros(len(pngs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    blob = torch.frombuffer(bytearray(b"".join(pngs)), dtype=torch.uint8)
+    tiles, status = ops.png_decode(blob.to(device), torch.from_numpy(offsets).to(device), size, size)
+    bad = torch.nonzero(status != 0).flatten().cpu().tolist()
+    for b in bad:
+        tiles[b] = torch.from_numpy(decode_png(pngs[b], size)).to(device)
+    return tiles
+
+
 def neighbor_tables(index: ShardIndex, k_neighbors: int, mode: str = "inverse", device=None):
     """Per-slide KNN + alpha on the device -> (neighbor_tile_ids int64 [N,K] pad -1, neighbor_alphas f32 [N,K] pad 0) in
     GLOBAL tile ids, and the edges map for the sampler."""
@@ -243,9 +259,12 @@ class ShardedSpatialDataModule:
         dev = torch.device("cuda", torch.cuda.current_device())
         for idx in sampler:
             pngs, sents = zip(*(index.read(i) for i in idx))
-            tiles = np.stack([decode_png(p, self.image_size) for p in pngs])
+            if os.environ.get("SC_PNG_HOST", "0") == "1":             # A/B: PIL on the host, as the reference's workers do
+                tiles = torch.from_numpy(np.stack([decode_png(p, self.image_size) for p in pngs])).to(dev)
+            else:
+                tiles = decode_png_batch(pngs, self.image_size, dev)
             params = draw_aug_params(len(idx), tiles.shape[1], tiles.shape[2], self.aug_cfg, rng, train)
-            images = ops.augment_tiles(torch.from_numpy(tiles).to(dev), params.to(dev), self.image_size, OPENAI_MEAN, OPENAI_STD)
+            images = ops.augment_tiles(tiles, params.to(dev), self.image_size, OPENAI_MEAN, OPENAI_STD)
             ids = torch.from_numpy(index.tile_ids[np.asarray(idx)])
             yield {"images": images, "texts": self._texts(list(sents)), "image_tile_ids": ids, "text_tile_ids": ids.clone(),
                    "neighbor_tile_ids": st["nbr"][np.asarray(idx)], "neighbor_alphas": st["alpha"][np.asarray(idx)],

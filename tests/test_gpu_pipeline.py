@@ -116,3 +116,51 @@ def test_shards_datamodule_feeds_the_trainer(tmp_path, monkeypatch):
     t.fit(m, dm)
     assert t.global_step == 12 and all(math.isfinite(h["train/loss"]) for h in t.history if "train/loss" in h)
     assert "val/loss" in t.history[-1] and math.isfinite(t.history[-1]["val/loss"])
+
+
+def test_png_tiles_decoded_on_the_device_equal_pil():
+    """sc_png_decode (one wave per tile: inflate + scanline filters on the device) against PIL on 224-pixel tiles of every
+    kind the core test covers -- noise (stored-like, two IDAT chunks), smooth / tissue-like (dynamic Huffman, long matches,
+    all filters), flat (long overlapping matches), RGBA, compress levels 0 / 1 / 9 -- BIT-EXACT; tiles it must decline
+    (wrong size, gray, truncated) come back with a non-zero status and are patched in by the host fallback."""
+    import io as _io
+    from PIL import Image
+    ops = _ops()
+    from spatial_clip_amd import shards
+    rng = np.random.default_rng(0)
+    H = W = 224
+    noise = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    smooth = np.asarray(Image.fromarray(rng.integers(0, 256, (30, 30, 3), dtype=np.uint8)).resize((W, H), Image.BICUBIC))
+    tissue = np.clip(smooth.astype(int) + rng.integers(-12, 13, (H, W, 3)), 0, 255).astype(np.uint8)
+    flat = np.full((H, W, 3), 200, np.uint8)
+    flat[50:100, 30:180] = (120, 40, 160)
+    rgba = np.dstack([tissue, rng.integers(0, 256, (H, W), dtype=np.uint8)])
+
+    def png(arr, **kw):
+        bio = _io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(arr)).save(bio, format="PNG", **kw)
+        return bio.getvalue()
+    files = [png(noise), png(smooth), png(tissue), png(flat), png(rgba), png(tissue, compress_level=0),
+             png(tissue, compress_level=1), png(tissue, compress_level=9), png(smooth, optimize=True)]
+    files += [png(np.clip(tissue.astype(int) + k, 0, 255).astype(np.uint8)) for k in range(23)]          # a fuller batch
+    n_good = len(files)
+    files += [png(tissue[:100, :100]), png(tissue[:, :, 0]), png(tissue)[:40000]]                        # declined: size, gray, cut
+    want = [np.asarray(Image.open(_io.BytesIO(f)).convert("RGB")) for f in files[:n_good]]
+    lens = np.array([len(f) for f in files], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    blob = torch.frombuffer(bytearray(b"".join(files)), dtype=torch.uint8).cuda()
+    out, status = ops.png_decode(blob, torch.from_numpy(offs).cuda(), H, W)
+    st = status.cpu().tolist()
+    assert st[:n_good] == [0] * n_good, st
+    assert st[n_good] == 10 and st[n_good + 1] == 9 and st[n_good + 2] != 0
+    o = out.cpu().numpy()
+    for b in range(n_good):
+        assert np.array_equal(o[b], want[b]), b
+    out2, status2 = ops.png_decode(blob, torch.from_numpy(offs).cuda(), H, W)            # no state carried between launches
+    assert torch.equal(out[:n_good], out2[:n_good])
+    # the data module's entry point: device decode + host fallback for what the kernel declined
+    good_small = png(np.asarray(Image.fromarray(tissue).resize((H, W))))
+    batch = shards.decode_png_batch([files[2], files[n_good + 1], good_small], H)
+    assert np.array_equal(batch[0].cpu().numpy(), want[2])
+    assert np.array_equal(batch[1].cpu().numpy(), np.asarray(Image.open(_io.BytesIO(files[n_good + 1])).convert("RGB")))
+    assert batch.shape == (3, H, W, 3)
