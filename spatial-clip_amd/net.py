@@ -51,7 +51,10 @@ class _NetFn(torch.autograd.Function):
         s = torch.empty(1, dtype=torch.float32, device=img.device)
         ops.exp_scalar(net.store.p("logit_scale").view(1), s)
         net._scale = s
-        return img, txt, s.view(())
+        # Return ALIASES, not the tensors the towers keep (tower.f): autograd stamps this node as grad_fn on the objects
+        # returned here, and a tensor that the net holds AND that points back at a node holding the net (ctx.net) is a
+        # reference cycle through C++ that Python's collector cannot see -- every net ever built would keep its HBM.
+        return img.detach(), txt.detach(), s.view(())
 
     @staticmethod
     def backward(ctx, d_img, d_txt, d_s):
