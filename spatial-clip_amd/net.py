@@ -179,6 +179,13 @@ class SpatialClipNet(torch.nn.Module):
             if stack is not None:
                 stack.set_grad_checkpointing(enable)
 
+    def reset_fp8_scaling(self) -> None:
+        """fp8 path: drop the per-tensor scales carried from the previous step (towers.TransformerStack.reset_fp8_scaling)."""
+        for tower in (self.vision, self.second):
+            stack = getattr(tower, "stack", None)
+            if stack is not None:
+                stack.reset_fp8_scaling()
+
     def _load_pretrained(self, pretrained: str) -> None:
         if os.path.isfile(pretrained):        # local checkpoint path branch of factory.py:418-421
             sd = torch.load(pretrained, map_location="cpu")

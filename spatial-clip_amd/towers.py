@@ -81,6 +81,15 @@ class TransformerStack:
     def set_grad_checkpointing(self, enable: bool = True) -> None:
         self.recompute = bool(enable)
 
+    def reset_fp8_scaling(self) -> None:
+        """Forget the delayed-scaling history (the next step runs the h / dU consumers in bf16 and records fresh maxima):
+        the fp8 path is a function of (weights, batch, scales of the previous step)."""
+        self._dq_ready = False
+        if self.fp8:
+            self._dq_scale.zero_()
+            self._dq_scale_inv.fill_(1.0)
+            self._dq_amax.zero_()
+
     def _act(self, kind: str, i: int, shape) -> torch.Tensor:
         """Buffer of a block's recomputable activation (a1 / a2 / h): one per block, or two rotating ones in
         recomputation mode (the CLS-only last block keeps its own: it runs first in the backward, nothing to rebuild)."""

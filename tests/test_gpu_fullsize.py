@@ -229,6 +229,7 @@ def test_configs4_per_gpu_batch_1024_with_recomputation_properties(precision):
     for rep in range(2):                 # the SAME model twice from the same initial weights (its ~177 GiB of buffers are reused)
         if rep:
             n.load_state_dict(init)
+            n.reset_fp8_scaling()       # fp8: the delayed scales are state too (a step is a function of the step before)
         oc = m.configure_optimizers()
         opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
         ls, gn = [], []
