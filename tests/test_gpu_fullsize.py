@@ -247,6 +247,8 @@ def test_configs4_per_gpu_batch_1024_with_recomputation_properties(precision):
     print(f"[configs4 {precision} B=1024 recompute] losses {l0}, grad norms {g0}, peak HBM {peak:.1f} GiB")
     assert all(x == x and abs(x) < 1e4 for x in l0 + g0)
     assert l0[:2] == l1 and g0[:2] == g1                      # bit-reproducible
-    assert l0[0] == l0[1]                                     # step 0 runs at lr = 0 (LambdaLR warm-up): same weights, same loss
+    # step 0 runs at lr = 0 (LambdaLR warm-up): same weights at step 1 -> the same loss, exactly in bf16; the fp8 path switches
+    # its h / dU consumers to e4m3 once the first step has recorded their maxima (delayed scaling): same loss to e4m3 noise
+    assert l0[0] == l0[1] if precision == "bf16" else abs(l0[0] - l0[1]) < 1e-3
     assert abs(l0[2] - l0[1]) < 0.5                           # one real AdamW step moves the loss, sanely (decrease: smaller tests)
     assert 120.0 < peak < 230.0, peak                          # DESIGN 4c': ~177 GiB with recomputation (233 GB without)
