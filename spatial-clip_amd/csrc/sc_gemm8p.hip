@@ -116,7 +116,6 @@ struct Stager {
     const bf16* src[4][2];      // [q][p] : this lane's source of the two 1-KiB pieces it copies per half-tile
     int nt;
     int wave;
-    int diag = 0;
 };
 
 // One phase of K tile `t` (ring parity D):  PH = 1..4  <->  quadrant (0,0) (0,1) (1,1) (1,0).
@@ -151,10 +150,8 @@ SC_DEVICE void phase(char* smem, const Stager& S, int t, const int (&a_off)[2], 
     constexpr int DS = PH <= 2 ? (D ^ 1) : D;
     const int ts = t + (PH <= 2 ? 1 : 2);
     if (ts < S.nt) {
-        if (!(S.diag & 4)) {                                  // SC_EPI_DIAG & 4: ablation without the operand stream
-            dma16(S.src[q][0] + (size_t)ts * BK, smem + slot(DS, q) + S.wave * 1024);
-            dma16(S.src[q][1] + (size_t)ts * BK, smem + slot(DS, q) + (8 + S.wave) * 1024);
-        }
+        dma16(S.src[q][0] + (size_t)ts * BK, smem + slot(DS, q) + S.wave * 1024);
+        dma16(S.src[q][1] + (size_t)ts * BK, smem + slot(DS, q) + (8 + S.wave) * 1024);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // retires the half-tile read in the NEXT phase
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ring is draining: fewer than four in flight
@@ -166,7 +163,6 @@ SC_DEVICE void phase(char* smem, const Stager& S, int t, const int (&a_off)[2], 
     constexpr int mi = PH >= 3 ? 1 : 0;
     constexpr int nj = (PH == 2 || PH == 3) ? 1 : 0;
     __builtin_amdgcn_s_setprio(1);
-    if (!(S.diag & 8)) {                                      // SC_EPI_DIAG & 8: ablation without the matrix work
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -175,12 +171,6 @@ SC_DEVICE void phase(char* smem, const Stager& S, int t, const int (&a_off)[2], 
             for (int jj = 0; jj < 2; ++jj)
                 acc[mi * 4 + ii][nj * 2 + jj] =
                     sc_mfma16(nj ? b1[kk * 2 + jj] : b0[kk * 2 + jj], a[kk * 4 + ii], acc[mi * 4 + ii][nj * 2 + jj]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(a[i]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(b0[i]), "v"(b1[i]));
-    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -217,7 +207,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
     Stager S;
     S.nt = (kend - kbeg) / BK;
     S.wave = wave;
-    S.diag = g.diag;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int r = (p * 8 + wave) * 8 + (lane >> 3);          // row of the half-tile image, 128 B per row
