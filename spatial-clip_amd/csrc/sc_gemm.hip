@@ -227,10 +227,6 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
     g.aux = (const bf16*)aux; g.ldaux = ldaux;
     g.colsum = nullptr; g.tile_offset = 0;
-    {
-        const char* dg = getenv("SC_EPI_DIAG");          // read per call (tools/bench_epi_diag.py)
-        g.diag = dg ? atoi(dg) : 0;
-    }
     // kernel choice: 256x256 phase-interleaved kernel (NT) -> 256x256 two-stage LDS-DMA kernel (TN, and NT when
     // pinned) -> 128x128 general kernel.  SC_GEMM_FORCE = 128 | 256 pins one kernel for A/B benchmarking.
     static const char* force = getenv("SC_GEMM_FORCE");

@@ -86,14 +86,9 @@ SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* st
                     union { u32x4 w; bf16x8 h; } x;
                     x.w = u;
                     bf16x8 o;
-                    if (g.diag & 2) {
-                        o = x.h;
-                    } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_gelu_fast((float)x.h[e]);
-                    }
-                    if (g.diag & 1) asm volatile("" ::"v"(o));
-                    else *reinterpret_cast<bf16x8*>(C2 + (size_t)grow * g.ldc2 + gcol) = o;
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_gelu_fast((float)x.h[e]);
+                    *reinterpret_cast<bf16x8*>(C2 + (size_t)grow * g.ldc2 + gcol) = o;
                     if (Q8 && g.q8) {                    // e4m3 copy of h for the c_proj forward GEMM (GemmArgs::q8)
                         float r[8];
 #pragma unroll

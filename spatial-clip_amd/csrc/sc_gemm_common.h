@@ -42,7 +42,6 @@ struct GemmArgs {
     const float* q8_scale = nullptr;
     float* q8_amax = nullptr;
     int a_scale_scalar = 0;
-    int diag = 0;         // SC_EPI_DIAG (benchmark diagnostics only): 1 = GELU pair without its second store, 2 = without the GELU arithmetic
 };
 
 constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes and reads)
