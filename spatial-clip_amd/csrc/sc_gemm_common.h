@@ -47,7 +47,7 @@ struct GemmArgs {
 constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes and reads)
 
 // exact-erf GELU to 1.5e-7 (Abramowitz-Stegun 7.1.26) sharing one exp between erf and the Gaussian pdf, arranged for the
-// fewest VALU issue slots (the GELU epilogues are VALU-bound while the matrix pipe idles: tools/bench_epi_diag.py):
+// fewest VALU issue slots (the GELU epilogues are VALU-bound while the matrix pipe idles: profiles/r03_gelu_epilogue_decomposition.txt):
 //   y = |x| sqrt(log2(e) / 2);  e = 2^(-y^2) = exp(-x^2 / 2);  t = 1 / (1 + p' y);  q(t) = poly(t) / 2
 //   erf(|x| / sqrt 2) = 1 - 2 q e   =>   gelu(x) = x Phi(x) = max(x, 0) - |x| q e
 //                                        gelu'(x) = Phi(x) + x phi(x) = [x >= 0] + e (x / sqrt(2 pi) - copysign(q, x))
