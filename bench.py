@@ -249,6 +249,12 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env}", file=sys.stderr)
         sys.exit(2)
 
+    # stdout carries ONE JSON line.  Libraries print there too (RCCL's version banner at communicator creation, for one):
+    # everything this process writes to file descriptor 1 goes to stderr until the line itself is printed.
+    sys.stdout.flush()
+    _stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import functools
@@ -447,7 +453,10 @@ def main():
                "loss_tolerance": LOSS_TOLERANCE[args.dtype],
                "parity": None if delta_init is None else {"initial_weights": delta_init, "after_training_steps": delta},
                "roofline": roofline, "cpu_baseline": cpu}
+        sys.stdout.flush()
+        os.dup2(_stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     comm.shutdown()
 
 
