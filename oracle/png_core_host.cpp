@@ -19,6 +19,17 @@ struct HostIO {
         if (seg >= h->nseg) return -1;
         return file[h->seg_off[seg] + pos++];
     }
+    int uniform(int v) { return v; }
+    int get_word(uint32_t& w) {
+        w = 0;
+        int nb = 0;
+        for (; nb < 4; ++nb) {
+            const int b = get_byte();
+            if (b < 0) break;
+            w |= (uint32_t)b << (8 * nb);
+        }
+        return nb;
+    }
     bool put_literal(int b) {
         if (n >= cap) return false;
         out[n++] = (uint8_t)b;

@@ -27,7 +27,7 @@ namespace {
 struct Lds {
     sc_png::Tables T;
     sc_png::Header h;
-    unsigned char in[1024];
+    unsigned in[256];                  // 1-KiB input window, read as dwords
     unsigned char stage[256];
 };
 
@@ -50,7 +50,7 @@ struct DevIO {
             if (left == 0) { ++seg; pos = 0; continue; }
             const int take = (int)min((unsigned)(1024 - fill), left);
             const unsigned char* src = file + L->h.seg_off[seg] + pos;
-            for (int i = lane; i < take; i += 64) L->in[fill + i] = src[i];
+            for (int i = lane; i < take; i += 64) reinterpret_cast<unsigned char*>(L->in)[fill + i] = src[i];
             fill += take;
             pos += take;
         }
@@ -63,7 +63,24 @@ struct DevIO {
             refill();
             if (in_fill == 0) return -1;
         }
-        return L->in[in_pos++];
+        return reinterpret_cast<unsigned char*>(L->in)[in_pos++];
+    }
+    __device__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    // the window is refilled in whole KiB (except the stream's tail), so a dword read is aligned whenever in_pos is
+    __device__ int get_word(unsigned& w) {
+        if (in_pos >= in_fill) {
+            refill();
+            if (in_fill == 0) { w = 0; return 0; }
+        }
+        if ((in_pos & 3) == 0 && in_pos + 4 <= in_fill) {
+            w = (unsigned)__builtin_amdgcn_readfirstlane((int)L->in[in_pos >> 2]);
+            in_pos += 4;
+            return 4;
+        }
+        w = 0;
+        int nb = 0;
+        for (; nb < 4 && in_pos < in_fill; ++nb) w |= (unsigned)reinterpret_cast<unsigned char*>(L->in)[in_pos++] << (8 * nb);
+        return nb;
     }
     __device__ void flush() {
         if (pending == 0) return;

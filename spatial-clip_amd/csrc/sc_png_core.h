@@ -7,6 +7,9 @@
 // match" into a copy by all 64.
 //
 // IO policy:   int  get_byte()                 next byte of the zlib stream, -1 past its end
+//              int  get_word(uint32_t& w)      next up-to-four bytes (little endian) -> how many are real (0 = end of stream)
+//              int  uniform(int v)             identity; the device policy returns lane 0's copy (v_readfirstlane), which tells
+//                                              the compiler that a table entry read from LDS is wave-uniform -> scalar ALU
 //              bool put_literal(int b)         append one byte to the output; false when the output is full
 //              bool copy_match(int dist, int len)   append len bytes starting dist bytes back (may overlap); false on a
 //                                              bad distance / overflow
@@ -46,12 +49,22 @@ struct BitReader {
     int cnt = 0;
     bool eof = false;
     SC_HD explicit BitReader(IO& i) : io(i) {}
+    // Refill in 32-bit gulps (io.get_word: up to four stream bytes, little endian, and how many of them are real): on the
+    // device every look-up is a dependent LDS round trip of ~100 cycles, so the input side must not add one per byte.
     SC_HD void fill(int need) {
         while (cnt < need && !eof) {
-            const int b = io.get_byte();
-            if (b < 0) { eof = true; break; }
-            buf |= (uint64_t)(unsigned)b << cnt;
-            cnt += 8;
+            if (cnt > 32) {                          // no room for a whole word: single bytes (only near `need` > 32, unused)
+                const int b = io.get_byte();
+                if (b < 0) { eof = true; break; }
+                buf |= (uint64_t)(unsigned)b << cnt;
+                cnt += 8;
+                continue;
+            }
+            uint32_t w = 0;
+            const int nb = io.get_word(w);
+            if (nb <= 0) { eof = true; break; }
+            buf |= (uint64_t)w << cnt;
+            cnt += 8 * nb;                           // nb < 4: a window / stream boundary; the next call tells which
         }
     }
     SC_HD int bits(int n) {             // n <= 16; -1 when the stream ends first
@@ -99,7 +112,7 @@ SC_HD int build(const uint8_t* len, int n, uint16_t* cnt, uint16_t* sym, uint16_
 template <class IO>
 SC_HD int decode_sym(BitReader<IO>& br, const uint16_t* cnt, const uint16_t* sym, const uint16_t* fast, int fast_bits) {
     br.fill(15);
-    const uint16_t e = fast[br.buf & ((1u << fast_bits) - 1)];
+    const uint16_t e = (uint16_t)br.io.uniform(fast[br.buf & ((1u << fast_bits) - 1)]);
     if (e) {
         const int l = e & 15;
         if (l > br.cnt) return -1;
@@ -113,8 +126,8 @@ SC_HD int decode_sym(BitReader<IO>& br, const uint16_t* cnt, const uint16_t* sym
         code |= (int)(br.buf & 1);
         br.buf >>= 1;
         br.cnt -= 1;
-        const int count = cnt[l];
-        if (code - count < first) return sym[index + (code - first)];
+        const int count = br.io.uniform(cnt[l]);
+        if (code - count < first) return br.io.uniform(sym[index + (code - first)]);
         index += count;
         first += count;
         first <<= 1;
