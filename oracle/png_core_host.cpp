@@ -20,6 +20,7 @@ struct HostIO {
         return file[h->seg_off[seg] + pos++];
     }
     int uniform(int v) { return v; }
+    template <class BR> void literal_run(BR&, const sc_png::Tables&) {}   // the device's wave-parallel fast path
     int get_word(uint32_t& w) {
         w = 0;
         int nb = 0;
@@ -30,13 +31,16 @@ struct HostIO {
         }
         return nb;
     }
+    long long n_lit = 0, n_match = 0, n_match_bytes = 0, n_far = 0;
     bool put_literal(int b) {
         if (n >= cap) return false;
         out[n++] = (uint8_t)b;
+        ++n_lit;
         return true;
     }
     bool copy_match(int dist, int len) {
         if (dist > n || n + len > cap) return false;
+        ++n_match; n_match_bytes += len; n_far += dist > 7900;
         for (int i = 0; i < len; ++i, ++n) out[n] = out[n - dist];
         return true;
     }
@@ -82,6 +86,22 @@ extern "C" int sc_png_host_decode(const uint8_t* file, long long n, uint8_t* out
         }
         free(prev); free(cur);
     }
+    free(buf); free(T);
+    return rc;
+}
+
+// symbol statistics of a file's DEFLATE stream (tools/bench_input_pipeline.py): literals, matches, matched bytes, matches
+// further back than an 8-KiB window would hold
+extern "C" int sc_png_host_stats(const uint8_t* file, long long n, long long* out4) {
+    sc_png::Header h;
+    int rc = sc_png::parse(file, n, h);
+    if (rc) return rc;
+    const long long raw = (long long)h.height * ((long long)h.width * h.channels + 1);
+    uint8_t* buf = (uint8_t*)malloc(raw);
+    sc_png::Tables* T = (sc_png::Tables*)malloc(sizeof(sc_png::Tables));
+    HostIO io{file, &h, 0, 0, buf, raw, 0};
+    rc = sc_png::inflate(io, *T);
+    out4[0] = io.n_lit; out4[1] = io.n_match; out4[2] = io.n_match_bytes; out4[3] = io.n_far;
     free(buf); free(T);
     return rc;
 }

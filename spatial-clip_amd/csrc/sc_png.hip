@@ -24,79 +24,104 @@
 
 namespace {
 
+constexpr int kWin = 2048;             // bytes of compressed input held in LDS
+
 struct Lds {
     sc_png::Tables T;
     sc_png::Header h;
-    unsigned in[256];                  // 1-KiB input window, read as dwords
-    unsigned char stage[256];
+    unsigned in[kWin / 4 + 2];         // input window, read as dwords (+2: the literal probe of the last lanes reads past its bits)
 };
 
 struct DevIO {
     const unsigned char* file;
     Lds* L;
     unsigned char* out;
-    long long cap, n;        // n: bytes committed to `out` (the stage holds `pending` more)
+    long long cap, n;        // n: bytes committed to `out` (`pending` more wait in `acc`)
     int lane;
     int seg;
     unsigned pos;            // cursor inside IDAT segment `seg`
     int in_pos, in_fill;
     int pending;
+    int acc;                 // up to 64 decoded literals, lane i holds literal i, stored as one 64-byte burst
+    int skip;                // literal_run back-off after a round that found (almost) no literals
 
-    __device__ void refill() {
+    // Every value that steers the decoder is wave-uniform, but the compiler only believes it for values it can prove so:
+    // whatever comes out of LDS is passed through v_readfirstlane (u()) and every function is force-inlined (a call passes
+    // `this` through memory), otherwise the whole control flow is compiled as divergent: exec-mask bookkeeping around every `if`.
+    static __device__ __forceinline__ int u(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+    // fill the window from byte `start` on with the next IDAT payload bytes (chunk boundaries are crossed here)
+    __device__ __forceinline__ void refill(int start) {
         __syncthreads();                                   // everybody is done with the old window
-        int fill = 0;
-        while (fill < 1024 && seg < L->h.nseg) {
-            const unsigned left = L->h.seg_len[seg] - pos;
+        int fill = start;
+        const int nseg = u(L->h.nseg);
+        while (fill < kWin && seg < nseg) {
+            const unsigned left = (unsigned)u((int)L->h.seg_len[seg]) - pos;
             if (left == 0) { ++seg; pos = 0; continue; }
-            const int take = (int)min((unsigned)(1024 - fill), left);
-            const unsigned char* src = file + L->h.seg_off[seg] + pos;
+            const int take = (int)min((unsigned)(kWin - fill), left);
+            const unsigned char* src = file + (unsigned)u((int)L->h.seg_off[seg]) + pos;
             for (int i = lane; i < take; i += 64) reinterpret_cast<unsigned char*>(L->in)[fill + i] = src[i];
             fill += take;
             pos += take;
         }
         in_fill = fill;
-        in_pos = 0;
         __syncthreads();
     }
-    __device__ int get_byte() {
+    // drop the bytes before `keep_from` (a multiple of 4; at most 256 bytes stay) and fill up behind what stays
+    __device__ __forceinline__ void slide(int keep_from) {
+        const int nd = (in_fill - keep_from + 3) >> 2;
+        __syncthreads();
+        unsigned v = 0;
+        if (lane < nd) v = L->in[(keep_from >> 2) + lane];
+        __syncthreads();
+        if (lane < nd) L->in[lane] = v;
+        in_pos -= keep_from;
+        refill(in_fill - keep_from);
+    }
+    __device__ __forceinline__ int get_byte() {
         if (in_pos >= in_fill) {
-            refill();
+            refill(0);
+            in_pos = 0;
             if (in_fill == 0) return -1;
         }
-        return reinterpret_cast<unsigned char*>(L->in)[in_pos++];
+        return u(reinterpret_cast<unsigned char*>(L->in)[in_pos++]);
     }
-    __device__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-    // the window is refilled in whole KiB (except the stream's tail), so a dword read is aligned whenever in_pos is
-    __device__ int get_word(unsigned& w) {
+    // up to four stream bytes: a whole dword when the cursor is aligned, otherwise the bytes up to the next dword boundary
+    __device__ __forceinline__ int get_word(unsigned& w) {
         if (in_pos >= in_fill) {
-            refill();
+            refill(0);
+            in_pos = 0;
             if (in_fill == 0) { w = 0; return 0; }
         }
         if ((in_pos & 3) == 0 && in_pos + 4 <= in_fill) {
-            w = (unsigned)__builtin_amdgcn_readfirstlane((int)L->in[in_pos >> 2]);
+            w = (unsigned)u((int)L->in[in_pos >> 2]);
             in_pos += 4;
             return 4;
         }
         w = 0;
         int nb = 0;
-        for (; nb < 4 && in_pos < in_fill; ++nb) w |= (unsigned)reinterpret_cast<unsigned char*>(L->in)[in_pos++] << (8 * nb);
+        const int lim = min(in_fill, (in_pos | 3) + 1);
+        for (; in_pos < lim; ++nb) w |= (unsigned)u(reinterpret_cast<unsigned char*>(L->in)[in_pos++]) << (8 * nb);
         return nb;
     }
-    __device__ void flush() {
+    __device__ __forceinline__ void flush() {
         if (pending == 0) return;
-        __syncthreads();                                   // the stage is complete
-        for (int i = lane; i < pending; i += 64) out[n + i] = L->stage[i];
-        __syncthreads();                                   // ... and may be overwritten
+        // (the wave barriers keep this lane-dependent branch from being merged with the uniform ones around it, which would
+        // turn the decoder's whole control flow divergent)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < pending) out[n + lane] = (unsigned char)acc;
+        __builtin_amdgcn_wave_barrier();
         n += pending;
         pending = 0;
     }
-    __device__ bool put_literal(int b) {
+    __device__ __forceinline__ bool put_literal(int b) {
         if (n + pending >= cap) return false;
-        if (lane == 0) L->stage[pending] = (unsigned char)b;
-        if (++pending == 256) flush();
+        acc = lane == pending ? b : acc;
+        if (++pending == 64) flush();
         return true;
     }
-    __device__ bool copy_match(int dist, int len) {
+    __device__ __forceinline__ bool copy_match(int dist, int len) {
         flush();
         if (dist > n || n + len > cap) return false;
         // the source run was written by other lanes (and possibly a moment ago): make those stores visible to this wave's loads
@@ -107,12 +132,65 @@ struct DevIO {
         n += len;
         return true;
     }
-    __device__ bool copy_stored(int k) {
+    __device__ __forceinline__ bool copy_stored(int k) {
         for (int i = 0; i < k; ++i) {
             const int b = get_byte();
             if (b < 0 || !put_literal(b)) return false;
         }
         return true;
+    }
+
+    // Runs of literals, 64 stream bits per round (photographs of tissue compress to literals only: 150,752 of them and not
+    // one match in the bench tile).  A Huffman stream is sequential because a code's position depends on the lengths of all
+    // codes before it -- but WHICH code starts at a given bit does not.  Lane k looks up the code that would start at bit
+    // cursor + k (one LDS look-up for 64 candidate positions); the wave then follows the chain 0 -> 0 + len -> ... through the
+    // lanes with v_readlane (a few scalar instructions per symbol instead of a dependent LDS round trip), dropping each
+    // literal into `acc`.  The chain stops at the first symbol that is not a short-coded literal (length / end-of-block
+    // symbols, codes longer than the look-up table): the scalar decoder takes that one and the next round starts behind it.
+    template <class BR>
+    __device__ __forceinline__ void literal_run(BR& br, const sc_png::Tables& T) {
+        if (skip > 0) { --skip; return; }
+        int c = in_pos * 8 - br.cnt;                       // stream cursor as a bit offset into the window
+        if (c < 0) return;                                 // the bit buffer still holds bytes of the previous window
+        bool moved = false;
+        for (;;) {
+            if (c + 80 > in_fill * 8) {                    // lane 63 needs bits up to c + 63 + kFastBitsL
+                if (in_fill < kWin) break;                 // the stream's tail: scalar
+                const int keep = (c >> 3) & ~3;
+                if (keep == 0) break;
+                slide(keep);
+                c -= keep * 8;
+                if (c + 80 > in_fill * 8) break;
+            }
+            if (n + pending + 64 > cap) break;             // a round emits at most 64 literals
+            const int bit = c + lane;
+            const unsigned lo = L->in[bit >> 5], hi = L->in[(bit >> 5) + 1];
+            const unsigned w = __builtin_amdgcn_alignbit(hi, lo, bit & 31);
+            const unsigned e = T.fast_l[w & ((1u << sc_png::kFastBitsL) - 1)];
+            const bool lit = e != 0 && e < (256u << 4);
+            const int pack = lit ? (int)((lane + (e & 15)) | ((e >> 4) << 8)) : -1;
+            int p = 0, got = 0;
+            while (p < 64) {
+                const int x = __builtin_amdgcn_readlane(pack, p);
+                if (x < 0) break;
+                acc = lane == pending ? x >> 8 : acc;
+                if (++pending == 64) flush();
+                p = x & 255;
+                ++got;
+            }
+            c += p;
+            moved = true;
+            if (p < 64) {                                  // stopped in front of a symbol for the scalar decoder
+                if (got < 2) skip = 8;
+                break;
+            }
+        }
+        if (moved) {                                       // re-seat the bit reader at the new cursor
+            in_pos = c >> 3;
+            br.buf = 0;
+            br.cnt = 0;
+            if (c & 7) br.bits(c & 7);
+        }
     }
 };
 
@@ -129,16 +207,16 @@ __global__ __launch_bounds__(64) void png_decode_kernel(const unsigned char* __r
         rc = nbytes > 0 ? sc_png::parse(file, nbytes, L.h) : sc_png::ERR_TRUNCATED;
         if (rc == sc_png::OK && (L.h.width != W || L.h.height != H)) rc = sc_png::ERR_SIZE;
     }
-    rc = __shfl(rc, 0, 64);
+    rc = __builtin_amdgcn_readfirstlane(rc);
     __syncthreads();
     if (rc != sc_png::OK) {
         if (lane == 0) status[b] = rc;
         return;
     }
-    const int bpp = L.h.channels, rowb = W * bpp, stride = rowb + 1;
+    const int bpp = __builtin_amdgcn_readfirstlane(L.h.channels), rowb = W * bpp, stride = rowb + 1;
     const long long raw = (long long)H * stride;
     unsigned char* buf = scratch + (long long)b * scratch_per_image;
-    DevIO io{file, &L, buf, raw, 0, lane, 0, 0u, 0, 0, 0};
+    DevIO io{file, &L, buf, raw, 0, lane, 0, 0u, 0, 0, 0, 0, 0};
     rc = sc_png::inflate(io, L.T);
     io.flush();
     if (rc == sc_png::OK && io.n != raw) rc = sc_png::ERR_TRUNCATED;

@@ -21,7 +21,7 @@
 
 #ifndef SC_HD
 #ifdef __HIPCC__
-#define SC_HD __host__ __device__ inline
+#define SC_HD __host__ __device__ __forceinline__
 #else
 #define SC_HD inline
 #endif
@@ -80,28 +80,40 @@ struct BitReader {
 };
 
 // canonical-code tables from code lengths len[0..n): counts, sorted symbols, and the fast look-up table
-SC_HD int build(const uint8_t* len, int n, uint16_t* cnt, uint16_t* sym, uint16_t* fast, int fast_bits) {
-    uint16_t offs[16];
-    for (int l = 0; l < 16; ++l) cnt[l] = 0;
-    for (int s = 0; s < n; ++s) cnt[len[s]]++;
-    if (cnt[0] == n) return 0;                       // no codes at all: legal for an unused distance alphabet
+template <class IO>
+SC_HD int build(IO& io, const uint8_t* len, int n, uint16_t* cnt, uint16_t* sym, uint16_t* fast, int fast_bits) {
+    int c[16], offs[16];                             // counts in registers: the tables themselves live in (device: LDS) memory
+    for (int l = 0; l < 16; ++l) c[l] = 0;
+    for (int s = 0; s < n; ++s) {
+        const int l = io.uniform(len[s]);
+        for (int k = 0; k < 16; ++k) c[k] += (k == l);
+    }
+    for (int l = 0; l < 16; ++l) cnt[l] = (uint16_t)c[l];
+    if (c[0] == n) return 0;                         // no codes at all: legal for an unused distance alphabet
     int left = 1;
     for (int l = 1; l < 16; ++l) {
         left <<= 1;
-        left -= cnt[l];
+        left -= c[l];
         if (left < 0) return -1;                     // over-subscribed
     }
     offs[1] = 0;
-    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + cnt[l];
-    for (int s = 0; s < n; ++s)
-        if (len[s]) sym[offs[len[s]]++] = (uint16_t)s;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + c[l];
+    for (int s = 0; s < n; ++s) {
+        const int l = io.uniform(len[s]);
+        if (l) {
+            int o = 0;
+            for (int k = 1; k < 16; ++k) { o += (k == l) ? offs[k] : 0; offs[k] += (k == l); }
+            sym[o] = (uint16_t)s;
+        }
+    }
     for (int i = 0; i < (1 << fast_bits); ++i) fast[i] = 0;
     int code = 0, idx = 0;
     for (int l = 1; l <= fast_bits; ++l) {
-        for (int k = 0; k < cnt[l]; ++k, ++code, ++idx) {
+        const int cl = io.uniform(cnt[l]);
+        for (int k = 0; k < cl; ++k, ++code, ++idx) {
             int rev = 0;                             // DEFLATE packs Huffman codes MSB first into an LSB-first stream
             for (int b = 0; b < l; ++b) rev |= ((code >> b) & 1) << (l - 1 - b);
-            const uint16_t e = (uint16_t)((sym[idx] << 4) | l);
+            const uint16_t e = (uint16_t)((io.uniform(sym[idx]) << 4) | l);
             for (int j = rev; j < (1 << fast_bits); j += 1 << l) fast[j] = e;
         }
         code <<= 1;
@@ -174,9 +186,9 @@ SC_HD int inflate(IO& io, Tables& T) {
         } else if (type == 1 || type == 2) {
             if (type == 1) {
                 fixed_lengths(T.len);
-                build(T.len, 288, T.cnt_l, T.sym_l, T.fast_l, kFastBitsL);
+                build(io, T.len, 288, T.cnt_l, T.sym_l, T.fast_l, kFastBitsL);
                 for (int s = 0; s < 30; ++s) T.len[s] = 5;
-                build(T.len, 30, T.cnt_d, T.sym_d, T.fast_d, kFastBitsD);
+                build(io, T.len, 30, T.cnt_d, T.sym_d, T.fast_d, kFastBitsD);
             } else {
                 const int hlit = br.bits(5), hdist = br.bits(5), hclen = br.bits(4);
                 if (hlit < 0 || hdist < 0 || hclen < 0) return ERR_TRUNCATED;
@@ -189,7 +201,7 @@ SC_HD int inflate(IO& io, Tables& T) {
                     T.len[order[i]] = (uint8_t)v;
                 }
                 // the code-length code borrows the distance tables (rebuilt below)
-                if (build(T.len, 19, T.cnt_d, T.sym_d, T.fast_d, 7) != 0) return ERR_CODE_LENGTHS;
+                if (build(io, T.len, 19, T.cnt_d, T.sym_d, T.fast_d, 7) != 0) return ERR_CODE_LENGTHS;
                 int i = 0;
                 while (i < nl + nd) {
                     const int s = decode_sym(br, T.cnt_d, T.sym_d, T.fast_d, 7);
@@ -200,7 +212,7 @@ SC_HD int inflate(IO& io, Tables& T) {
                         int prev = 0, rep;
                         if (s == 16) {
                             if (i == 0) return ERR_CODE_LENGTHS;
-                            prev = T.len[19 + i - 1];
+                            prev = io.uniform(T.len[19 + i - 1]);
                             rep = 3 + br.bits(2);
                             if (rep < 3) return ERR_TRUNCATED;
                         } else if (s == 17) {
@@ -214,14 +226,15 @@ SC_HD int inflate(IO& io, Tables& T) {
                         while (rep--) T.len[19 + i++] = (uint8_t)prev;
                     }
                 }
-                if (T.len[19 + 256] == 0) return ERR_CODE_LENGTHS;            // no end-of-block code
+                if (io.uniform(T.len[19 + 256]) == 0) return ERR_CODE_LENGTHS;            // no end-of-block code
                 // the two builds read T.len[19..]; build() does not write T.len
-                const int rl = build(T.len + 19, nl, T.cnt_l, T.sym_l, T.fast_l, kFastBitsL);
+                const int rl = build(io, T.len + 19, nl, T.cnt_l, T.sym_l, T.fast_l, kFastBitsL);
                 if (rl < 0 || (rl > 0 && nl - T.cnt_l[0] != 1)) return ERR_CODE_LENGTHS;
-                const int rd = build(T.len + 19 + nl, nd, T.cnt_d, T.sym_d, T.fast_d, kFastBitsD);
+                const int rd = build(io, T.len + 19 + nl, nd, T.cnt_d, T.sym_d, T.fast_d, kFastBitsD);
                 if (rd < 0 || (rd > 0 && nd - T.cnt_d[0] != 1)) return ERR_CODE_LENGTHS;
             }
             for (;;) {
+                io.literal_run(br, T);                   // device: a wave-parallel run of literals; elsewhere a no-op
                 int s = decode_sym(br, T.cnt_l, T.sym_l, T.fast_l, kFastBitsL);
                 if (s < 0) return br.eof ? ERR_TRUNCATED : ERR_SYMBOL;
                 if (s < 256) {

@@ -164,3 +164,77 @@ def test_png_tiles_decoded_on_the_device_equal_pil():
     assert np.array_equal(batch[0].cpu().numpy(), want[2])
     assert np.array_equal(batch[1].cpu().numpy(), np.asarray(Image.open(_io.BytesIO(files[n_good + 1])).convert("RGB")))
     assert batch.shape == (3, H, W, 3)
+
+
+def test_png_decode_odd_sizes_many_chunks_and_mixed_streams():
+    """The wave-parallel literal path of sc_png_decode (64 candidate code positions per round, window slides, re-seated bit
+    reader) against zlib / PIL where its bookkeeping is stressed: IDAT payloads cut into many small chunks at arbitrary byte
+    positions, literal runs interleaved with matches (a tissue patch tiled over the image), rows that are no multiple of
+    anything, every zlib strategy (Huffman-only = literals with long codes, RLE, fixed codes, filtered)."""
+    import io as _io
+    import struct
+    import zlib
+    from PIL import Image
+    ops = _ops()
+    rng = np.random.default_rng(5)
+
+    def hand_png(arr, chunk, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, filt=None):
+        h, w, c = arr.shape
+        raw = bytearray()
+        prev = np.zeros((w, c), np.int32)
+        for y in range(h):
+            row = arr[y].astype(np.int32)
+            ft = (y % 5) if filt is None else filt
+            left = np.vstack([np.zeros((1, c), np.int32), row[:-1]])
+            ul = np.vstack([np.zeros((1, c), np.int32), prev[:-1]])
+            if ft == 0:
+                d = row
+            elif ft == 1:
+                d = row - left
+            elif ft == 2:
+                d = row - prev
+            elif ft == 3:
+                d = row - ((left + prev) >> 1)
+            else:
+                pa, pb, pc = np.abs(prev - ul), np.abs(left - ul), np.abs(left + prev - 2 * ul)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+                d = row - pred
+            raw += bytes([ft]) + (d & 255).astype(np.uint8).tobytes()
+            prev = row
+        co = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
+        z = co.compress(bytes(raw)) + co.flush()
+
+        def ch(tag, data):
+            return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+        out = b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0))
+        for i in range(0, len(z), chunk):
+            out += ch(b"IDAT", z[i:i + chunk])
+        return out + ch(b"IEND", b"")
+
+    for (H, W) in [(96, 96), (53, 37), (16, 16), (7, 300)]:
+        small = rng.integers(0, 256, (max(H // 8, 2), max(W // 8, 2), 3), dtype=np.uint8)
+        smooth = np.asarray(Image.fromarray(small).resize((W, H), Image.BICUBIC))
+        tissue = np.clip(smooth.astype(int) + rng.integers(-12, 13, (H, W, 3)), 0, 255).astype(np.uint8)
+        patch = tissue[:max(H // 3, 2), :max(W // 3, 2)]
+        tiled = np.tile(patch, (4, 4, 1))[:H, :W]                                    # literal runs between matches
+        rgba = np.dstack([tissue, rng.integers(0, 256, (H, W), dtype=np.uint8)])
+        files = []
+        for arr in (tissue, tiled, rgba):
+            n_bytes = len(zlib.compress(arr.tobytes(), 6))
+            for chunk in (max(n_bytes // 30 + 1, 7), 997, 1 << 20):                  # <= 32 chunks (the kernel's limit)
+                files.append(hand_png(arr, chunk))
+            files.append(hand_png(arr, 1 << 20, 6, zlib.Z_HUFFMAN_ONLY))
+            files.append(hand_png(arr, 1 << 20, 6, zlib.Z_RLE))
+            files.append(hand_png(arr, 1 << 20, 6, zlib.Z_FIXED))
+            files.append(hand_png(arr, 1 << 20, 9, zlib.Z_FILTERED, filt=4))
+            files.append(hand_png(arr, 1 << 20, 1, filt=0))
+        files = [f for f in files if f.count(b"IDAT") <= 32]
+        want = [np.asarray(Image.open(_io.BytesIO(f)).convert("RGB")) for f in files]
+        lens = np.array([len(f) for f in files], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        blob = torch.frombuffer(bytearray(b"".join(files)), dtype=torch.uint8).cuda()
+        out, status = ops.png_decode(blob, torch.from_numpy(offs).cuda(), H, W)
+        assert status.cpu().tolist() == [0] * len(files), (H, W, status.cpu().tolist())
+        o = out.cpu().numpy()
+        for b in range(len(files)):
+            assert np.array_equal(o[b], want[b]), (H, W, b)
