@@ -144,8 +144,8 @@ struct DevIO {
     // one match in the bench tile).  A Huffman stream is sequential because a code's position depends on the lengths of all
     // codes before it -- but WHICH code starts at a given bit does not.  Lane k looks up the code that would start at bit
     // cursor + k (one LDS look-up for 64 candidate positions); the wave then follows the chain 0 -> 0 + len -> ... through the
-    // lanes with v_readlane (a few scalar instructions per symbol instead of a dependent LDS round trip), dropping each
-    // literal into `acc`.  The chain stops at the first symbol that is not a short-coded literal (length / end-of-block
+    // lanes with v_readlane (a few scalar instructions per symbol instead of a dependent LDS round trip) and the lanes
+    // on the chain store their literals.  The chain stops at the first symbol that is not a short-coded literal (length / end-of-block
     // symbols, codes longer than the look-up table): the scalar decoder takes that one and the next round starts behind it.
     template <class BR>
     __device__ __forceinline__ void literal_run(BR& br, const sc_png::Tables& T) {
@@ -153,6 +153,7 @@ struct DevIO {
         int c = in_pos * 8 - br.cnt;                       // stream cursor as a bit offset into the window
         if (c < 0) return;                                 // the bit buffer still holds bytes of the previous window
         bool moved = false;
+        flush();                                           // the rounds store behind what the scalar path collected
         for (;;) {
             if (c + 80 > in_fill * 8) {                    // lane 63 needs bits up to c + 63 + kFastBitsL
                 if (in_fill < kWin) break;                 // the stream's tail: scalar
@@ -162,22 +163,42 @@ struct DevIO {
                 c -= keep * 8;
                 if (c + 80 > in_fill * 8) break;
             }
-            if (n + pending + 64 > cap) break;             // a round emits at most 64 literals
+            if (n + 64 > cap) break;                       // a round emits at most 64 literals
             const int bit = c + lane;
             const unsigned lo = L->in[bit >> 5], hi = L->in[(bit >> 5) + 1];
             const unsigned w = __builtin_amdgcn_alignbit(hi, lo, bit & 31);
             const unsigned e = T.fast_l[w & ((1u << sc_png::kFastBitsL) - 1)];
             const bool lit = e != 0 && e < (256u << 4);
-            const int pack = lit ? (int)((lane + (e & 15)) | ((e >> 4) << 8)) : -1;
-            int p = 0, got = 0;
-            while (p < 64) {
-                const int x = __builtin_amdgcn_readlane(pack, p);
-                if (x < 0) break;
-                acc = lane == pending ? x >> 8 : acc;
-                if (++pending == 64) flush();
-                p = x & 255;
-                ++got;
+            // next position of the chain from this lane; bit 6 ends the walk (a literal that ends at or past bit 64 -- or, with
+            // bit 7, a symbol the walk must stop IN FRONT of)
+            const int next = lit ? lane + (int)(e & 15) : 0xC0 | lane;
+            unsigned long long mask;                       // the lanes on the chain
+            int p;
+            // four scalar issue slots per symbol (+2 wait states: a v_readlane result may not select the next v_readlane's
+            // lane earlier than 4 states later); the compiler's version of this loop took 17 with three branches
+            asm volatile("s_mov_b64 %0, 0\n\t"
+                         "s_mov_b32 %1, 0\n"
+                         "sc_png_chase_%=:\n\t"
+                         "s_bitset1_b64 %0, %1\n\t"
+                         "s_nop 1\n\t"
+                         "v_readlane_b32 %1, %2, %1\n\t"
+                         "s_bitcmp0_b32 %1, 6\n\t"
+                         "s_cbranch_scc1 sc_png_chase_%=\n\t"
+                         : "=&s"(mask), "=&s"(p)
+                         : "v"(next)
+                         : "scc");
+            if (p & 0x80) {                                // stopped in front of lane p & 63, which the walk marked
+                p &= 63;
+                mask &= ~(1ull << p);
             }
+            // the chain's literals leave in stream order: lane -> rank among the chain's lanes (the bytes of one round are
+            // adjacent, the L2 merges the partial lines of successive rounds)
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            __builtin_amdgcn_wave_barrier();
+            if ((mask >> lane) & 1) out[n + rank] = (unsigned char)(e >> 4);
+            __builtin_amdgcn_wave_barrier();
+            const int got = __builtin_popcountll(mask);
+            n += got;
             c += p;
             moved = true;
             if (p < 64) {                                  // stopped in front of a symbol for the scalar decoder

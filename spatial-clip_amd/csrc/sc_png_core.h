@@ -133,6 +133,9 @@ SC_HD int decode_sym(BitReader<IO>& br, const uint16_t* cnt, const uint16_t* sym
         return e >> 4;
     }
     int code = 0, first = 0, index = 0;              // canonical walk, one bit at a time (codes longer than fast_bits)
+#ifdef SC_PNG_STATS
+    ++sc_png_stats_long_codes;
+#endif
     for (int l = 1; l <= 15; ++l) {
         if (br.cnt < 1) return -1;
         code |= (int)(br.buf & 1);
