@@ -3,19 +3,19 @@
 // PIL on CPU dataloader workers).  At ~7.5 k pairs/s per GPU the host cannot inflate ~1.1 GB/s of zlib streams, so the
 // compressed files are copied to HBM as they are and decoded next to their consumer (sc_augment_tiles).
 //
-// One wave per tile.  A DEFLATE stream is sequential, so the parallelism is ACROSS tiles (a batch is 256 of them); within a
-// tile the 64 lanes run the decoder's control flow with identical values (sc_png_core.h, the same source the CPU test
-// harness compiles) and help where the format allows it:
-//   * input   the IDAT payloads are pulled through a 1-KiB LDS window, refilled by all lanes (chunk boundaries handled there);
-//   * output  literals collect in a 256-byte LDS stage and leave as one coalesced store burst; an LZ77 match is ONE
-//             wave-wide gather / scatter whatever its length (an overlapping match repeats with period `dist`, so lane i reads
-//             byte i mod dist of the source run) -- stores and the later loads of other lanes are ordered by workgroup-scope
-//             release / acquire fences (one wave = one workgroup: a wait, no cache maintenance);
-//   * filters PNG's Sub / Up / Average / Paeth predictors depend on the left, upper and upper-left neighbours: 64 rows are
-//             reconstructed together, row r one pixel behind row r - 1, and the neighbours of the row above arrive by
-//             lane shifts (no memory round trip inside a band).
-// Footprint: 5 KiB of LDS, 138 VGPRs, one wave per workgroup: it runs wherever a SIMD has room (beside LayerNorm / loss /
-// optimiser kernels; the 256x256 GEMM workgroups fill the register file on their own).
+// One wave per tile; the parallelism is across tiles (the data module inflates several batches per launch) and, inside a
+// tile, wherever the format allows it.  The decoder's control state is wave-uniform and kept in SGPRs (sc_png_core.h, the same
+// source the CPU test harness compiles, with the device policy below):
+//   * input    the IDAT payloads are pulled through a 2-KiB LDS window, refilled or slid by all lanes (chunk boundaries there);
+//   * literals 64 stream bits per round: every lane looks up the code that would start at ITS bit, the wave walks the chain of
+//              code starts with v_readlane and the lanes on the chain store their literals (DevIO::literal_run);
+//   * matches  an LZ77 match is ONE wave-wide gather / scatter whatever its length (an overlapping match repeats with period
+//              `dist`, so lane i reads byte i mod dist of the source run) -- stores and the later loads of other lanes are
+//              ordered by workgroup-scope release / acquire fences (one wave = one workgroup: a wait, no cache maintenance);
+//   * filters  PNG's Sub / Up / Average / Paeth predictors depend on the left, upper and upper-left neighbours: 64 rows are
+//              reconstructed together, row r one pixel behind row r - 1, and the neighbours of the row above arrive by
+//              lane shifts (no memory round trip inside a band).
+// Footprint: 5.9 KiB of LDS, 82 VGPRs, one wave per workgroup: five waves per SIMD, and it runs wherever a SIMD has room.
 // Limits (anything else sets status != 0 and the host decodes that tile with PIL): 8-bit RGB / RGBA, no interlace, tile
 // size = the requested H x W, at most 32 IDAT chunks.
 #include "sc_common.h"
@@ -36,7 +36,7 @@ struct DevIO {
     const unsigned char* file;
     Lds* L;
     unsigned char* out;
-    long long cap, n;        // n: bytes committed to `out` (`pending` more wait in `acc`)
+    int cap, n;              // n: bytes committed to `out` (`pending` more wait in `acc`); H (4 W + 1) < 2^31 is checked at launch
     int lane;
     int seg;
     unsigned pos;            // cursor inside IDAT segment `seg`
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void png_decode_kernel(const unsigned char* __r
         return;
     }
     const int bpp = __builtin_amdgcn_readfirstlane(L.h.channels), rowb = W * bpp, stride = rowb + 1;
-    const long long raw = (long long)H * stride;
+    const int raw = H * stride;
     unsigned char* buf = scratch + (long long)b * scratch_per_image;
     DevIO io{file, &L, buf, raw, 0, lane, 0, 0u, 0, 0, 0, 0, 0};
     rc = sc_png::inflate(io, L.T);
@@ -260,21 +260,36 @@ __global__ __launch_bounds__(64) void png_decode_kernel(const unsigned char* __r
         const int ft = active ? row[0] : 0;
         if (ft > 4) bad_filter = true;
         int left[4] = {0, 0, 0, 0}, last1[4] = {0, 0, 0, 0}, last2[4] = {0, 0, 0, 0};
+        // the bytes of pixel x + 1 (and, for lane 0, of the pixel above it) are requested before pixel x is rebuilt and stored:
+        // one exposed memory latency per pixel step would otherwise be the whole cost of this stage
+        int cur[4] = {0, 0, 0, 0}, upc[4] = {0, 0, 0, 0}, upprev[4] = {0, 0, 0, 0};
+        auto load_px = [&](int x, int (&dst)[4], int (&updst)[4]) {
+            const bool on = active && x >= 0 && x < W;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c >= bpp) break;
+                dst[c] = on ? row[1 + x * bpp + c] : 0;
+                if (lane == 0) updst[c] = (on && y > 0) ? above[1 + x * bpp + c] : 0;
+            }
+        };
+        load_px(-lane, cur, upc);
         for (int t = 0; t < W + 63; ++t) {
             const int x = t - lane;
             const bool on = active && x >= 0 && x < W;
+            int nxt[4] = {0, 0, 0, 0}, upn[4] = {0, 0, 0, 0};
+            load_px(x + 1, nxt, upn);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (c >= bpp) break;
                 int up = __shfl_up(last1[c], 1, 64), ul = __shfl_up(last2[c], 1, 64);
                 if (lane == 0) {
-                    up = (on && y > 0) ? above[1 + x * bpp + c] : 0;
-                    ul = (on && y > 0 && x > 0) ? above[1 + (x - 1) * bpp + c] : 0;
+                    up = upc[c];
+                    ul = upprev[c];                        // the pixel above x - 1 (zeros in front of the row)
                 }
                 if (on) {
                     const int a = x > 0 ? left[c] : 0;
                     if (x == 0) ul = 0;
-                    int v = row[1 + x * bpp + c];
+                    int v = cur[c];
                     if (ft == 1) v += a;
                     else if (ft == 2) v += up;
                     else if (ft == 3) v += (a + up) >> 1;
@@ -285,7 +300,10 @@ __global__ __launch_bounds__(64) void png_decode_kernel(const unsigned char* __r
                     left[c] = v;
                     last2[c] = last1[c];
                     last1[c] = v;
+                    upprev[c] = upc[c];
                 }
+                cur[c] = nxt[c];
+                upc[c] = upn[c];
             }
         }
         // the next band's first row reads this band's last row from memory
@@ -308,6 +326,7 @@ extern "C" int sc_png_decode(const void* files, const long long* offsets, int B,
                              int* status, void* stream) {
     SC_CHECK(B >= 1 && H >= 1 && W >= 1 && files && offsets && out_rgb && scratch && status,
              "sc_png_decode: bad arguments B=%d H=%d W=%d", B, H, W);
+    SC_CHECK((long long)H * (4LL * W + 1) < (1LL << 31), "sc_png_decode: tile %d x %d too large", H, W);
     const long long per = sc_png_decode_scratch_bytes(1, H, W);
     png_decode_kernel<<<B, 64, 0, (hipStream_t)stream>>>((const unsigned char*)files, offsets, (unsigned char*)out_rgb, H, W,
                                                          (unsigned char*)scratch, per, status);

@@ -17,6 +17,7 @@ Tile ids are global int64 row indices over (sorted slide ids, member order) like
 from __future__ import annotations
 
 import io
+import itertools
 import json
 import math
 import os
@@ -192,7 +193,7 @@ class ShardedSpatialDataModule:
                  dataset_format_kwargs: Optional[Dict[str, Any]] = None, splits: Optional[Dict[str, Any]] = None,
                  image_size: int = 224, n_genes: Optional[int] = None, gene_vocab: Optional[Sequence[str]] = None,
                  aug_cfg: Optional[Dict[str, Any]] = None, alpha_mode: str = "inverse", seed: int = 2025,
-                 centers_per_batch: int = 16, max_neighbors_per_center: int = 4):
+                 centers_per_batch: int = 16, max_neighbors_per_center: int = 4, decode_ahead: int = 8):
         if dataset_format != "shards_v1":
             raise ValueError(f"dataset_format {dataset_format!r}: this module reads 'shards_v1' "
                              "(synthetic batches: data.SyntheticSpatialDataModule)")
@@ -202,6 +203,9 @@ class ShardedSpatialDataModule:
         self.n_genes = n_genes
         self.gene_to_idx = {g: i for i, g in enumerate(gene_vocab)} if gene_vocab else None
         self.centers_per_batch, self.max_neighbors_per_center = centers_per_batch, max_neighbors_per_center
+        # batches whose PNG files are inflated by ONE sc_png_decode launch: a tile is one wave of dependent scalar steps, so
+        # the cost per tile falls 7x between 256 and 8192 tiles per launch (profiles/r03_png_batch_scaling.txt)
+        self.decode_ahead = max(1, int(decode_ahead))
         self.preprocess_fn: Optional[Callable] = None
         self.tokenizer: Optional[Callable] = None
         self._sets: Dict[str, Dict[str, Any]] = {}
@@ -257,18 +261,27 @@ class ShardedSpatialDataModule:
             sampler = self._eval_index_batches(len(index), self.batch_size, rank, W)
         rng = np.random.default_rng([self.seed, epoch, rank, 0 if train else 1])
         dev = torch.device("cuda", torch.cuda.current_device())
-        for idx in sampler:
-            pngs, sents = zip(*(index.read(i) for i in idx))
+        it = iter(sampler)
+        while True:
+            group = list(itertools.islice(it, self.decode_ahead))
+            if not group:
+                return
+            flat = [i for idx in group for i in idx]
+            pngs, sents = zip(*(index.read(i) for i in flat))
             if os.environ.get("SC_PNG_HOST", "0") == "1":             # A/B: PIL on the host, as the reference's workers do
-                tiles = torch.from_numpy(np.stack([decode_png(p, self.image_size) for p in pngs])).to(dev)
+                tiles_all = torch.from_numpy(np.stack([decode_png(p, self.image_size) for p in pngs])).to(dev)
             else:
-                tiles = decode_png_batch(pngs, self.image_size, dev)
-            params = draw_aug_params(len(idx), tiles.shape[1], tiles.shape[2], self.aug_cfg, rng, train)
-            images = ops.augment_tiles(tiles, params.to(dev), self.image_size, OPENAI_MEAN, OPENAI_STD)
-            ids = torch.from_numpy(index.tile_ids[np.asarray(idx)])
-            yield {"images": images, "texts": self._texts(list(sents)), "image_tile_ids": ids, "text_tile_ids": ids.clone(),
-                   "neighbor_tile_ids": st["nbr"][np.asarray(idx)], "neighbor_alphas": st["alpha"][np.asarray(idx)],
-                   "raw_text": list(sents)}
+                tiles_all = decode_png_batch(pngs, self.image_size, dev)
+            at = 0
+            for idx in group:
+                tiles, s_b = tiles_all[at:at + len(idx)], list(sents[at:at + len(idx)])
+                at += len(idx)
+                params = draw_aug_params(len(idx), tiles.shape[1], tiles.shape[2], self.aug_cfg, rng, train)
+                images = ops.augment_tiles(tiles, params.to(dev), self.image_size, OPENAI_MEAN, OPENAI_STD)
+                ids = torch.from_numpy(index.tile_ids[np.asarray(idx)])
+                yield {"images": images, "texts": self._texts(s_b), "image_tile_ids": ids, "text_tile_ids": ids.clone(),
+                       "neighbor_tile_ids": st["nbr"][np.asarray(idx)], "neighbor_alphas": st["alpha"][np.asarray(idx)],
+                       "raw_text": s_b}
 
     def _loader(self, name: str, train: bool):
         if name not in self._sets:

@@ -112,6 +112,15 @@ def test_shards_datamodule_feeds_the_trainer(tmp_path, monkeypatch):
         ids = set(b["image_tile_ids"].tolist())
         hits += sum(1 for v in b["neighbor_tile_ids"].flatten().tolist() if v in ids)
     assert hits > 0.3 * 12 * 4 * len(batches), hits             # the sampler keeps neighbours in the batch
+    # the batches do not depend on how many of them one sc_png_decode launch inflates (decode_ahead: 8 above, 1 and 4 here)
+    for ahead in (1, 4):
+        dm.decode_ahead = ahead
+        again = list(dm.train_dataloader())
+        assert len(again) == len(batches)
+        for a, b in zip(again, batches):
+            assert torch.equal(a["images"], b["images"]) and torch.equal(a["image_tile_ids"], b["image_tile_ids"])
+            assert a["raw_text"] == b["raw_text"]
+    dm.decode_ahead = 8
     t = trainer.Trainer(max_epochs=2, gradient_clip_val=1.0, log_every_n_steps=1)
     t.fit(m, dm)
     assert t.global_step == 12 and all(math.isfinite(h["train/loss"]) for h in t.history if "train/loss" in h)
