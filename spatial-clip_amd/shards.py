@@ -16,18 +16,21 @@ Tile ids are global int64 row indices over (sorted slide ids, member order) like
 (notebooks/d1_dataset_construct_cw.ipynb).  Batches are drawn by the neighbour-aware sampler (sampler.py)."""
 from __future__ import annotations
 
+import contextlib
 import io
 import itertools
 import json
 import math
 import os
+import queue
 import tarfile
+import threading
 from typing import Any, Callable, Dict, Iterator, List, Optional, Sequence
 
 import numpy as np
 import torch
 
-from . import comm, ops
+from . import comm, ops, streams
 from .sampler import SpatialBucketBatchSampler, build_fast_indices
 
 OPENAI_MEAN = (0.48145466, 0.4578275, 0.40821073)
@@ -81,12 +84,44 @@ class ShardIndex:
 
     def read(self, i: int):
         e = self.entries[i]
-        with open(e["tar"], "rb") as f:
-            f.seek(e["png"][0])
-            png = f.read(e["png"][1])
-            f.seek(e["txt"][0])
-            txt = f.read(e["txt"][1]).decode("utf-8")
-        return png, txt
+        fd = self._fd(e["tar"])
+        return os.pread(fd, e["png"][1], e["png"][0]), self.text(i)
+
+    # ---- the batch producer's forms: one descriptor per tar for the life of the index, PNG bytes read straight into the
+    # (pinned) staging buffer, sentences read once
+    def _fd(self, tar: str) -> int:
+        fds = self.__dict__.setdefault("_fds", {})
+        fd = fds.get(tar)
+        if fd is None:
+            fd = fds[tar] = os.open(tar, os.O_RDONLY)
+        return fd
+
+    def png_size(self, i: int) -> int:
+        return self.entries[i]["png"][1]
+
+    def read_png_into(self, i: int, dst: memoryview) -> None:
+        e = self.entries[i]
+        got = os.preadv(self._fd(e["tar"]), [dst], e["png"][0])
+        if got != e["png"][1]:
+            raise IOError(f"{e['tar']}: short read of tile {i} ({got} of {e['png'][1]} bytes)")
+
+    def text(self, i: int) -> str:
+        cache = self.__dict__.setdefault("_txt", {})
+        t = cache.get(i)
+        if t is None:
+            e = self.entries[i]
+            t = cache[i] = os.pread(self._fd(e["tar"]), e["txt"][1], e["txt"][0]).decode("utf-8")
+        return t
+
+    def close(self) -> None:
+        for fd in self.__dict__.pop("_fds", {}).values():
+            os.close(fd)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def decode_png(png: bytes, size: Optional[int] = None) -> np.ndarray:
@@ -96,7 +131,7 @@ def decode_png(png: bytes, size: Optional[int] = None) -> np.ndarray:
     im = Image.open(io.BytesIO(png)).convert("RGB")
     if size is not None and im.size != (size, size):
         im = im.resize((size, size), Image.BILINEAR)
-    return np.asarray(im, dtype=np.uint8)
+    return np.array(im, dtype=np.uint8)
 
 
 def decode_png_batch(pngs: Sequence[bytes], size: int, device=None) -> torch.Tensor:
@@ -184,6 +219,46 @@ def rank_weighted_vector(sentence: str, gene_to_idx: Dict[str, int], n_genes: in
     return v
 
 
+def rank_weighted_sparse(sentence: str, gene_to_idx: Dict[str, int]):
+    """The non-zeros of ``rank_weighted_vector``: (gene indices int64 [n], weights f32 [n]), each gene once (its first =
+    heaviest occurrence)."""
+    genes = [g for g in sentence.split() if g in gene_to_idx]
+    first: Dict[int, float] = {}
+    for r, g in enumerate(genes):
+        first.setdefault(gene_to_idx[g], 1.0 - r / max(len(genes), 1))
+    return (np.fromiter(first.keys(), dtype=np.int64, count=len(first)),
+            np.fromiter(first.values(), dtype=np.float32, count=len(first)))
+
+
+class _PinnedRing:
+    """Two pinned staging buffers used in turn; a buffer is handed out again only after the copy that last read it is done."""
+
+    def __init__(self):
+        self.buf = [None, None]
+        self.done = [None, None]
+        self.k = 0
+
+    def take(self, nbytes: int) -> torch.Tensor:
+        self.k ^= 1
+        if self.done[self.k] is not None:
+            self.done[self.k].synchronize()
+        b = self.buf[self.k]
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8)
+            if torch.cuda.is_available():
+                b = b.pin_memory()
+            self.buf[self.k] = b
+        return b
+
+    def copied(self, stream) -> None:
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.done[self.k] = ev
+
+
+_END = object()
+
+
 class ShardedSpatialDataModule:
     """``SpatialClipDataModule`` constructor kwargs (spatial_datamodule.py:21-31) with ``dataset_format="shards_v1"``;
     ``splits`` maps "train" / "val" / "test" to lists of slide ids."""
@@ -247,7 +322,40 @@ class ShardedSpatialDataModule:
             order = (order + order[:total - n])[rank::W] if total > n else order[rank::W]
         return [order[i:i + bs] for i in range(0, len(order), bs)]
 
-    def _batches(self, name: str, train: bool) -> Iterator[Dict[str, Any]]:
+    def _texts_of(self, st: Dict[str, Any], flat: Sequence[int], dev) -> torch.Tensor:
+        """The second tower's input for tiles ``flat``, built on the device.  A tile's sentence never changes, so it is read
+        and tokenised once (gene towers: the non-zeros of its rank-weighted vector; text tower: its BPE ids) -- the dense
+        [B, n_genes] array of a batch is a scatter of ~50 values per row, not 20 000-float rows built in Python."""
+        index: ShardIndex = st["index"]
+        cache = st.setdefault("tok", {})
+        if self.gene_to_idx is not None:
+            n = self.n_genes or len(self.gene_to_idx)
+            rows, cols, ws = [], [], []
+            for r, i in enumerate(flat):
+                t = cache.get(i)
+                if t is None:
+                    t = cache[i] = rank_weighted_sparse(index.text(i), self.gene_to_idx)
+                rows.append(np.full(len(t[0]), r, dtype=np.int64))
+                cols.append(t[0])
+                ws.append(t[1])
+            out = torch.zeros((len(flat), n), dtype=torch.float32, device=dev)
+            if rows:
+                out.index_put_((torch.from_numpy(np.concatenate(rows)).to(dev), torch.from_numpy(np.concatenate(cols)).to(dev)),
+                               torch.from_numpy(np.concatenate(ws)).to(dev))
+            return out
+        toks = []
+        for i in flat:
+            t = cache.get(i)
+            if t is None:
+                t = cache[i] = self.tokenizer([index.text(i)])[0]
+            toks.append(t)
+        return torch.stack(toks).to(dev)
+
+    def _produce(self, name: str, train: bool, dev, stream) -> Iterator[Any]:
+        """(batch, event) pairs in training order.  ``decode_ahead`` batches form a group: their PNG files are read straight
+        into a pinned buffer, copied to HBM in one piece and inflated by ONE ``sc_png_decode`` launch; augmentation and the
+        second tower's input follow per batch.  All device work is enqueued on ``stream`` (None: the caller's), and the event
+        marks the point where the batch is complete."""
         st = self._sets[name]
         index: ShardIndex = st["index"]
         rank, W = comm.world()
@@ -260,28 +368,110 @@ class ShardedSpatialDataModule:
         else:
             sampler = self._eval_index_batches(len(index), self.batch_size, rank, W)
         rng = np.random.default_rng([self.seed, epoch, rank, 0 if train else 1])
-        dev = torch.device("cuda", torch.cuda.current_device())
+        host_decode = os.environ.get("SC_PNG_HOST", "0") == "1"      # A/B: PIL on the host, as the reference's workers do
+        ring = self.__dict__.setdefault("_ring", _PinnedRing())
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         it = iter(sampler)
         while True:
             group = list(itertools.islice(it, self.decode_ahead))
             if not group:
                 return
             flat = [i for idx in group for i in idx]
-            pngs, sents = zip(*(index.read(i) for i in flat))
-            if os.environ.get("SC_PNG_HOST", "0") == "1":             # A/B: PIL on the host, as the reference's workers do
-                tiles_all = torch.from_numpy(np.stack([decode_png(p, self.image_size) for p in pngs])).to(dev)
-            else:
-                tiles_all = decode_png_batch(pngs, self.image_size, dev)
-            at = 0
-            for idx in group:
-                tiles, s_b = tiles_all[at:at + len(idx)], list(sents[at:at + len(idx)])
-                at += len(idx)
-                params = draw_aug_params(len(idx), tiles.shape[1], tiles.shape[2], self.aug_cfg, rng, train)
-                images = ops.augment_tiles(tiles, params.to(dev), self.image_size, OPENAI_MEAN, OPENAI_STD)
-                ids = torch.from_numpy(index.tile_ids[np.asarray(idx)])
-                yield {"images": images, "texts": self._texts(s_b), "image_tile_ids": ids, "text_tile_ids": ids.clone(),
-                       "neighbor_tile_ids": st["nbr"][np.asarray(idx)], "neighbor_alphas": st["alpha"][np.asarray(idx)],
-                       "raw_text": s_b}
+            sizes = np.fromiter((index.png_size(i) for i in flat), dtype=np.int64, count=len(flat))
+            offsets = np.zeros(len(flat) + 1, dtype=np.int64)
+            np.cumsum(sizes, out=offsets[1:])
+            total = int(offsets[-1])
+            host = ring.take(total)
+            mv = memoryview(host.numpy())
+            for j, i in enumerate(flat):
+                index.read_png_into(i, mv[offsets[j]:offsets[j + 1]])
+            with ctx:
+                cur = torch.cuda.current_stream()
+                if host_decode:
+                    tiles_all = torch.from_numpy(np.stack([decode_png(bytes(mv[offsets[j]:offsets[j + 1]]), self.image_size)
+                                                           for j in range(len(flat))])).to(dev)
+                else:
+                    blob = host[:total].to(dev, non_blocking=True)
+                    ring.copied(cur)
+                    tiles_all, status = ops.png_decode(blob, torch.from_numpy(offsets).to(dev), self.image_size, self.image_size)
+                    for j in torch.nonzero(status != 0).flatten().cpu().tolist():       # declined by the kernel: PIL
+                        tiles_all[j] = torch.from_numpy(decode_png(bytes(mv[offsets[j]:offsets[j + 1]]), self.image_size)).to(dev)
+                at = 0
+                for idx in group:
+                    rows = flat[at:at + len(idx)]
+                    tiles = tiles_all[at:at + len(idx)]
+                    at += len(idx)
+                    params = draw_aug_params(len(idx), tiles.shape[1], tiles.shape[2], self.aug_cfg, rng, train)
+                    images = ops.augment_tiles(tiles, params.to(dev), self.image_size, OPENAI_MEAN, OPENAI_STD)
+                    ids = torch.from_numpy(index.tile_ids[np.asarray(idx)])
+                    batch = {"images": images, "texts": self._texts_of(st, rows, dev), "image_tile_ids": ids,
+                             "text_tile_ids": ids.clone(), "neighbor_tile_ids": st["nbr"][np.asarray(idx)],
+                             "neighbor_alphas": st["alpha"][np.asarray(idx)], "raw_text": [index.text(i) for i in rows]}
+                    ev = None
+                    if stream is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(cur)
+                    yield batch, ev
+
+    def _batches(self, name: str, train: bool) -> Iterator[Dict[str, Any]]:
+        """Batches of split ``name``.  A producer thread runs ``_produce`` one group ahead on its own HIP stream, so file
+        reads, the H2D copy, PNG inflation and augmentation of the next steps overlap the training step that is running
+        (the reference's counterpart: DataLoader worker processes + pinned-memory thread, spatial_datamodule.py:91-101);
+        ``SC_DATA_THREAD=0`` produces inline on the caller's stream."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if os.environ.get("SC_DATA_THREAD", "1") == "0":
+            for batch, _ in self._produce(name, train, dev, None):
+                yield batch
+            return
+        side = self.__dict__.get("_side")
+        if side is None:
+            side = self._side = torch.cuda.Stream(device=dev)
+        q: "queue.Queue[Any]" = queue.Queue(maxsize=2 * self.decode_ahead)
+        stop = threading.Event()
+
+        def put(item) -> bool:
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                for item in self._produce(name, train, dev, side):
+                    if not put(item):
+                        return
+                put(_END)
+            except BaseException as e:          # noqa: BLE001 -- handed to the consumer, which re-raises it
+                put(e)
+
+        th = threading.Thread(target=work, name=f"sc-data-{name}", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is _END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                batch, ev = item
+                users = streams.consumer_streams()
+                users[0].wait_event(ev)
+                for v in batch.values():        # allocated on the producer's stream, read on the consumer's
+                    if isinstance(v, torch.Tensor) and v.is_cuda:
+                        for u in users:
+                            v.record_stream(u)
+                yield batch
+        finally:
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)
 
     def _loader(self, name: str, train: bool):
         if name not in self._sets:

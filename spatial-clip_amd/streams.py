@@ -32,3 +32,11 @@ def chain_stream():
     with torch.cuda.stream(s):
         yield s
     cur.wait_stream(s)
+
+
+def consumer_streams():
+    """The caller's current stream and, when it exists, this device's chain stream: the streams that will read a tensor
+    handed to the training loop by another stream (data producer -> ``Tensor.record_stream``)."""
+    cur = torch.cuda.current_stream()
+    s = _chain.get(torch.cuda.current_device())
+    return [cur] if s is None or s == cur else [cur, s]

@@ -147,6 +147,17 @@ def test_shard_index_reads_reference_layout(tmp_path):
     assert tile.shape == (8, 8, 3) and tile[0, 0].tolist() == [80, 0, 251]
     assert shards.decode_png(png, 16).shape == (16, 16, 3)
     assert idx.xy[4].tolist() == [5.0, 7.0]
+    buf = bytearray(idx.png_size(4) + 8)                       # the batch producer's form: straight into a staging buffer
+    idx.read_png_into(4, memoryview(buf)[3:3 + idx.png_size(4)])
+    assert bytes(buf[3:3 + idx.png_size(4)]) == png and idx.text(4) == txt and idx.text(4) is idx.text(4)
+    rng = np.random.default_rng(0)
+    vocab = {f"G{i}": i for i in range(40)}
+    for _ in range(20):                                         # sparse and dense forms of the gene vector agree
+        sent = " ".join(rng.choice([f"G{i}" for i in range(60)], size=int(rng.integers(0, 30))))
+        cols, w = shards.rank_weighted_sparse(sent, vocab)
+        dense = np.zeros(40, np.float32)
+        dense[cols] = w
+        assert np.array_equal(dense, shards.rank_weighted_vector(sent, vocab, 40)) and len(set(cols.tolist())) == len(cols)
     only_b = shards.ShardIndex(root, ["SAMPLE_B"])
     assert len(only_b) == 9 and set(only_b.sample_ids) == {"SAMPLE_B"}
     with pytest.raises(FileNotFoundError):

@@ -121,6 +121,22 @@ def test_shards_datamodule_feeds_the_trainer(tmp_path, monkeypatch):
             assert torch.equal(a["images"], b["images"]) and torch.equal(a["image_tile_ids"], b["image_tile_ids"])
             assert a["raw_text"] == b["raw_text"]
     dm.decode_ahead = 8
+    monkeypatch.setenv("SC_DATA_THREAD", "0")                  # ... nor on whether a producer thread / side stream prepares them
+    inline = list(dm.train_dataloader())
+    monkeypatch.delenv("SC_DATA_THREAD")
+    assert all(torch.equal(a["images"], b["images"]) and torch.equal(a["texts"], b["texts"]) for a, b in zip(inline, batches))
+    half = []                                                   # a consumer that stops early leaves no thread behind
+    for b in dm.train_dataloader():
+        half.append(b)
+        if len(half) == 2:
+            break
+    import threading
+    import time as _time
+    _time.sleep(0.5)
+    assert not [t for t in threading.enumerate() if t.name.startswith("sc-data-")]
+    from spatial_clip_amd import shards as _sh
+    dense = np.stack([_sh.rank_weighted_vector(t, {g: i for i, g in enumerate(genes)}, len(genes)) for t in batches[0]["raw_text"]])
+    assert np.array_equal(batches[0]["texts"].cpu().numpy(), dense)
     t = trainer.Trainer(max_epochs=2, gradient_clip_val=1.0, log_every_n_steps=1)
     t.fit(m, dm)
     assert t.global_step == 12 and all(math.isfinite(h["train/loss"]) for h in t.history if "train/loss" in h)
