@@ -263,3 +263,35 @@ def test_png_decode_odd_sizes_many_chunks_and_mixed_streams():
         o = out.cpu().numpy()
         for b in range(len(files)):
             assert np.array_equal(o[b], want[b]), (H, W, b)
+
+
+def test_png_decode_of_damaged_files_agrees_with_the_cpu_build_of_its_core():
+    """240 files, 237 of them damaged (tests/test_cpu_png.py::damaged_files; the CPU build of the shared core survives them
+    under AddressSanitizer): the kernel reports an error exactly where the CPU build does, returns the same pixels where
+    the damage still decodes, and the intact files around them are not disturbed."""
+    import ctypes
+    import __graft_entry__ as ge
+    from tests.test_cpu_png import damaged_files
+    ops = _ops()
+    H = W = 64
+    files = damaged_files(237, H, W)
+    host = ctypes.CDLL(ge.build_png_core_host())
+    host.sc_png_host_decode.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    want_rc, want_px = [], []
+    for f in files:
+        out = np.zeros((H, W, 3), np.uint8)
+        buf = (ctypes.c_ubyte * max(len(f), 1)).from_buffer_copy(f if f else b"\0")
+        want_rc.append(host.sc_png_host_decode(buf, len(f), out.ctypes.data, H, W))
+        want_px.append(out)
+    keep = [k for k, f in enumerate(files) if len(f) > 0]             # an empty file has no bytes to point at
+    lens = np.array([len(files[k]) for k in keep], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    blob = torch.frombuffer(bytearray(b"".join(files[k] for k in keep)), dtype=torch.uint8).cuda()
+    out, status = ops.png_decode(blob, torch.from_numpy(offs).cuda(), H, W)
+    st = status.cpu().tolist()
+    o = out.cpu().numpy()
+    for j, k in enumerate(keep):
+        assert (st[j] == 0) == (want_rc[k] == 0), (k, st[j], want_rc[k])
+        if st[j] == 0:
+            assert np.array_equal(o[j], want_px[k]), k
+    assert st[:3] == [0, 0, 0] and sum(s != 0 for s in st) > 100
