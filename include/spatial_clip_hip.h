@@ -84,6 +84,17 @@ int sc_layernorm_bwd_q8(const void* dy, long long lddy, const float* x, long lon
                         const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
                         long long lddbf, void* dres_fp8, long long ldd8, float* scale_inv, int accumulate,
                         float* dgamma, float* dbeta, float* colsum, float* ws, int rows, int d, void* stream);
+/* LayerNorm backward with the residual gradient carried in bf16 -- the precision the reference carries it in: under its
+ * bf16 autocast the residual stream x + attn(ln_1(x)) (src/open_clip/transformer.py:253,260-264) and hence its gradient
+ * are bf16 tensors.  gout = gin + LNbwd(dy) is read and written in bf16 only (10 instead of 16 bytes per element cross
+ * HBM); the fp32 buffer is read for the sparse form (accumulate = -P: the incoming gradient of rows r % P == 0 sits
+ * there) and written only when write_f32 != 0 (the last hop, in front of the embedding backward).  gout_fp8 / scale_inv
+ * as in sc_layernorm_bwd_q8, or null.  dgamma / dbeta / colsum and the deferred reduction as in sc_layernorm_bwd. */
+int sc_layernorm_bwd_g16(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
+                         const float* rstd, const float* gamma, const void* gin_bf16, long long ldgin, float* dres,
+                         long long lddres, int write_f32, void* gout_bf16, long long ldgout, void* gout_fp8,
+                         long long ldd8, float* scale_inv, int accumulate, float* dgamma, float* dbeta, float* colsum,
+                         float* ws, int rows, int d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ attention
  * Fused multi-head self-attention on the packed in_proj output qkv[B*L, 3*H*dh] (q | k | v, head h at

@@ -171,16 +171,32 @@ def gelu_bf16(u: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, colsum, rows: int, d: int, *,
                   accumulate, lddy=None, ldx=None, lddres=None, lddbf=None, ws=None, defer_reduce: bool = False,
-                  q8: Optional[torch.Tensor] = None, q8_scale_inv: Optional[torch.Tensor] = None):
+                  q8: Optional[torch.Tensor] = None, q8_scale_inv: Optional[torch.Tensor] = None,
+                  g_in: Optional[torch.Tensor] = None, ldgin=None, write_f32: bool = True, g16: bool = False):
     """``accumulate``: False / True, or a negative int -P: only rows r % P == 0 of ``dres`` carry an incoming gradient.
     ``defer_reduce``: leave the per-block partial sums of dgamma / dbeta / colsum in ``ws`` (caller-owned, at least
-    layernorm_bwd_ws_floats floats) and finish them with layernorm_bwd_reduce -- e.g. on the weight-gradient stream."""
+    layernorm_bwd_ws_floats floats) and finish them with layernorm_bwd_reduce -- e.g. on the weight-gradient stream.
+    ``g16`` (sc_layernorm_bwd_g16): the residual gradient travels in bf16 -- the incoming one is ``g_in`` (bf16) when
+    ``accumulate`` is True, the outgoing one ``dres_bf16``; the fp32 ``dres`` is written only if ``write_f32``."""
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.float32, "x"); _req(dres, torch.float32, "dres")
     l = _lib.lib()
     if ws is None:
         if defer_reduce:
             raise _lib.SpatialClipHipError("layernorm_bwd: defer_reduce needs a caller-owned workspace")
         ws = workspace(l.sc_layernorm_bwd_ws_floats(rows, d), dy.device, "ln")
+    if g16:
+        if int(accumulate) > 0:
+            _req(g_in, torch.bfloat16, "g_in")
+        _req(dres_bf16, torch.bfloat16, "dres_bf16")
+        if q8 is not None:
+            _req(q8_scale_inv, torch.float32, "q8_scale_inv")
+        check(l.sc_layernorm_bwd_g16(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
+                                     gamma.data_ptr(), _ptr(g_in), ldgin or d, dres.data_ptr(), lddres or d, int(write_f32),
+                                     dres_bf16.data_ptr(), lddbf or d, _ptr(q8), q8.stride(0) if q8 is not None else 0,
+                                     _ptr(q8_scale_inv), int(accumulate),
+                                     None if defer_reduce else dgamma.data_ptr(), dbeta.data_ptr(), _ptr(colsum),
+                                     ws.data_ptr(), rows, d, _stream()), "sc_layernorm_bwd_g16")
+        return
     if q8 is not None:          # e4m3 copy of the new residual gradient + per-row 1/scale (A operand of the fp8 dgrad GEMMs)
         if q8.dtype != torch.uint8 or not q8.is_cuda or q8.stride(-1) != 1:
             raise TypeError("layernorm_bwd: q8 must be a device uint8 matrix")

@@ -242,7 +242,8 @@ class TransformerStack:
         ops.layernorm_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
                           s.p(self._n(i, "ln_1.weight")), dres, dres_bf, g("ln_1.weight"), g("ln_1.bias"),
                           prev_bias, M, d, accumulate=-L,       # only the class-token rows carry a residual gradient
-                          q8=qg and qg[0], q8_scale_inv=qg and qg[1])
+                          q8=qg and qg[0], q8_scale_inv=qg and qg[1],
+                          g16=_res_grad_bf16(), write_f32=(i == 0))  # bf16 stream: fp32 only in front of the stem
         self._g_q8 = qg
         return dres, dres_bf
 
@@ -303,16 +304,23 @@ class TransformerStack:
         # LN2).  Producer and consumer are both on the chain stream, back to back: ONE scratch is enough.
         qg = self._q8("g", M, d)
 
-        def ln_bwd(dy, x, mean, rstd, gamma, g_bf, dgamma, dbeta, colsum) -> None:
-            q8kw = dict(q8=qg[0], q8_scale_inv=qg[1]) if qg is not None else {}
+        # The residual gradient between the blocks travels in bf16 (g_in -> g_bf, three rotating buffers), which is the
+        # precision the reference's autocast carries it in; the fp32 buffer is written by the stack's last hop only (the
+        # stem reads it).  SC_RES_GRAD=fp32 keeps the fp32 read-modify-write of rounds 1-2 (16 instead of 10 bytes per element).
+        g16 = _res_grad_bf16()
+
+        def ln_bwd(dy, x, mean, rstd, gamma, g_in, g_bf, dgamma, dbeta, colsum, last=False) -> None:
+            kw = dict(q8=qg[0], q8_scale_inv=qg[1]) if qg is not None else {}
+            if g16:
+                kw.update(g16=True, g_in=g_in, write_f32=last)
             if not overlap:
-                ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, g_bf, dgamma, dbeta, colsum, M, d, accumulate=True, **q8kw)
+                ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, g_bf, dgamma, dbeta, colsum, M, d, accumulate=True, **kw)
                 return
             ws = ln_ws[ln_pos[0] % 4]
             ln_pos[0] += 1
             before_write(ws)
             ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, g_bf, dgamma, dbeta, colsum, M, d, accumulate=True,
-                              ws=ws, defer_reduce=True, **q8kw)
+                              ws=ws, defer_reduce=True, **kw)
             on_side(lambda: ops.layernorm_bwd_reduce(ws, dgamma, dbeta, colsum, M, d), (ws,))
 
         def dgrad(epi, g_bf, name, out, *, N, K, have_q8, **kw) -> None:
@@ -381,7 +389,7 @@ class TransformerStack:
             g1 = ring[rpos]
             before_write(g1)
             ln_bwd(dA, xmid, bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32),
-                   s.p(self._n(i, "ln_2.weight")), g1, g("ln_2.weight"), g("ln_2.bias"), g("attn.out_proj.bias"))
+                   s.p(self._n(i, "ln_2.weight")), g0, g1, g("ln_2.weight"), g("ln_2.bias"), g("attn.out_proj.bias"))
             # ---- attention branch: xmid = x_in + out_proj(attn(in_proj(ln_1(x_in))))
             dgrad(ops.EPI_BF16, g1, self._n(i, "attn.out_proj.weight"), dO, N=d, K=d, have_q8=qg is not None)
             before_write(dqkv)
@@ -403,7 +411,7 @@ class TransformerStack:
             g2 = ring[rpos]
             before_write(g2)
             ln_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
-                   s.p(self._n(i, "ln_1.weight")), g2, g("ln_1.weight"), g("ln_1.bias"), prev_bias)
+                   s.p(self._n(i, "ln_1.weight")), g1, g2, g("ln_1.weight"), g("ln_1.bias"), prev_bias, last=(i == 0))
             g_has_q8 = qg is not None
             if on_layer_done is not None:
                 on_side(lambda i=i: on_layer_done(i), ())     # the bucket all-reduce follows the side stream
@@ -415,6 +423,11 @@ class TransformerStack:
             ev.record(side)
             main.wait_event(ev)
         return dres
+
+def _res_grad_bf16() -> bool:
+    """Read at every backward: SC_RES_GRAD=fp32 restores the fp32 residual-gradient buffer (A/B, tests)."""
+    return os.environ.get("SC_RES_GRAD", "bf16") != "fp32"
+
 
 class PatchTransformerTower:
     """Patch embedding (one bias-free linear map per patch) + class token + learned positions + ln_pre + N residual
