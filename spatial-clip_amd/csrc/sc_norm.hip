@@ -43,8 +43,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      unsigned char* __restrict__ y8, long long ldy8,
                                                      float* __restrict__ scale_inv) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    // Rows are walked LAST ROW FIRST: the producer in front (a GEMM walking its tiles upwards) wrote the high rows last, so
+    // they are the ones still in the 256-MB Infinity Cache; and the rows this kernel writes last are the low ones the next
+    // GEMM reads first.  Same-box A/B of the whole step: -0.19 ms (profiles/r03_ln_row_order_ab.txt).
+    const int row = rows - 1 - (blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row < 0) return;
     const float* xr = x + (long long)row * ldx;
     const int nv = d >> 2;
     f32x4 v[NV];
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         const int e = i * 64 + lane;
         gm[i] = e < nv ? ld4(gamma + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int row_ = blockIdx.x * 4 + wave; row_ < rows; row_ += gridDim.x * 4) {
+        const int row = rows - 1 - row_;              // last row first: see ln_fwd_kernel
         const float mu = mean[row], rs = rstd[row];
         const bf16* dyr = dy + (long long)row * lddy;
         const float* xr = x + (long long)row * ldx;
