@@ -240,6 +240,8 @@ def main():
                     help="activation recomputation (LayerNorm outputs, GELU output): configs[4] at 1024 pairs per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: e4m3 forward GEMMs of the transformer blocks (BASELINE configs[4]); backward stays bf16")
+    ap.add_argument("--residual-stream", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: the forward residual stream kept in bf16 like the reference's autocast (default fp32)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -265,7 +267,8 @@ def main():
         print(f"bench.py: live process group has {dist.get_world_size()} ranks, wanted {args.gpus}", file=sys.stderr)
         sys.exit(2)
 
-    n = net.SpatialClipNet(args.model, None, n_genes=args.n_genes, seed=0, precision=args.dtype)
+    n = net.SpatialClipNet(args.model, None, n_genes=args.n_genes, seed=0, precision=args.dtype,
+                           residual_stream=args.residual_stream)
     cfg = n.cfg
     if args.grad_checkpointing:
         n.model.set_grad_checkpointing(True)
@@ -444,7 +447,8 @@ def main():
                                       f"{'ClipLoss' if args.loss == 'clip' else 'SpatialLoss(k=8)'} over global batch {G}, "
                                       "fwd+bwd+grad-allreduce+clip+AdamW" +
                                       (", activation recomputation (LN outputs, GELU output)" if args.grad_checkpointing else "")),
-                          "global_batch": G,
+                          "global_batch": G, "residual_stream": n.residual_stream if not os.environ.get("SC_RES_STREAM")
+                          else os.environ["SC_RES_STREAM"],
                           "parallelism": f"dp{world}", "loss": float(loss.detach())},
                "n_gpus_live": dist.get_world_size() if world > 1 else 1,
                "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),

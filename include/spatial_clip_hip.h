@@ -35,12 +35,14 @@ int sc_abi_version(void);
  *   SC_EPI_GELU_PAIR     C(bf16) = u = acc + bias ; C2(bf16) = gelu_erf(u)  (mlp.c_fc + nn.GELU)
  *   SC_EPI_BF16_DGELU    C(bf16) = acc * gelu'(aux[M,N](bf16))          (c_proj dgrad fused with GELU bwd)
  *   SC_EPI_F32           C(f32)  = acc ; with splitk > 1 partial slabs go to `slabs` and are reduced into C
+ *   SC_EPI_BF16_BIAS_RES C(bf16) = acc + bias[N] + res[M,N](bf16)       (residual stream kept in bf16, as the reference's
+ *                        autocast keeps it; `res` then points at bf16 data and ldres counts bf16 elements; one rounding)
  * N % 8 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.  Outer-dimension edges are handled. */
 enum { SC_GEMM_NT = 0, SC_GEMM_TN = 1 };
 enum { SC_EPI_BF16 = 0, SC_EPI_BF16_BIAS = 1, SC_EPI_F32_BIAS_RES = 2, SC_EPI_GELU_PAIR = 3,
-       SC_EPI_BF16_DGELU = 4, SC_EPI_F32 = 5 };
+       SC_EPI_BF16_DGELU = 4, SC_EPI_F32 = 5, SC_EPI_BF16_BIAS_RES = 6 };
 int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
-                 void* C, int ldc, void* C2, int ldc2, const float* bias, const float* res, int ldres,
+                 void* C, int ldc, void* C2, int ldc2, const float* bias, const void* res, int ldres,
                  const void* aux, int ldaux, int splitk, float* slabs, void* stream);
 long long sc_gemm_slab_floats(int M, int N, int K, int splitk);
 /* Weight AND bias gradient of one Linear in one pass: dW[M,N](f32) = dY[K,M]^T . X[K,N], dbias[M] = column sums of dY
@@ -60,7 +62,7 @@ int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long ld_src, int 
                          long long ld_dst, float* scale_inv, float fixed_scale, void* stream);
 int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
                 const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2, const float* bias,
-                const float* res, int ldres, const void* aux, int ldaux, void* stream);
+                const void* res, int ldres, const void* aux, int ldaux, void* stream);
 /* sc_gemm_fp8 with (a) a_scale_scalar != 0: a_scale_inv points at ONE factor for all rows of A8 (an operand quantised
  * with a per-tensor scale) and (b) an optional e4m3 copy of the epilogue's bf16 output (SC_EPI_GELU_PAIR: h;
  * SC_EPI_BF16_DGELU: dU) for the next GEMM: q8_out[M][ldq8] = e4m3(value * *q8_scale), and max|value| of the launch is
@@ -69,7 +71,7 @@ int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, cons
  * slots: "delayed scaling" -- a tile cannot know its rows' maxima, the step before can. */
 int sc_gemm_fp8_q(int epi, const void* A8, int lda, const float* a_scale_inv, int a_scale_scalar, const void* B8, int ldb,
                   const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2, const float* bias,
-                  const float* res, int ldres, const void* aux, int ldaux, void* q8_out, long long ldq8,
+                  const void* res, int ldres, const void* aux, int ldaux, void* q8_out, long long ldq8,
                   const float* q8_scale, float* q8_amax, void* stream);
 int sc_fp8_scale_update(float* amax_slots, float* scale, float* scale_inv, int n, int margin_bits, void* stream);
 /* The quantiser fused into the kernels that hold a complete row (round 3): LayerNorm forward also emits the e4m3 copy
@@ -91,6 +93,17 @@ int sc_layernorm_bwd_q8(const void* dy, long long lddy, const float* x, long lon
  * there) and written only when write_f32 != 0 (the last hop, in front of the embedding backward).  gout_fp8 / scale_inv
  * as in sc_layernorm_bwd_q8, or null.  dgamma / dbeta / colsum and the deferred reduction as in sc_layernorm_bwd. */
 int sc_layernorm_bwd_g16(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
+                         const float* rstd, const float* gamma, const void* gin_bf16, long long ldgin, float* dres,
+                         long long lddres, int write_f32, void* gout_bf16, long long ldgout, void* gout_fp8,
+                         long long ldd8, float* scale_inv, int accumulate, float* dgamma, float* dbeta, float* colsum,
+                         float* ws, int rows, int d, void* stream);
+/* The same two passes on a residual stream that is kept in bf16 (SC_EPI_BF16_BIAS_RES writes it): x points at bf16 rows,
+ * ldx counts bf16 elements.  y_fp8 / gout_fp8 + scale_inv as in the _q8 forms or null; gin_bf16 null = the incoming
+ * gradient (if accumulate != 0) is read from the fp32 buffer as in sc_layernorm_bwd. */
+int sc_layernorm_fwd_x16(const void* x_bf16, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
+                         void* y_fp8, long long ldy8, float* scale_inv, float* mean, float* rstd, int rows, int d,
+                         float eps, void* stream);
+int sc_layernorm_bwd_x16(const void* dy, long long lddy, const void* x_bf16, long long ldx, const float* mean,
                          const float* rstd, const float* gamma, const void* gin_bf16, long long ldgin, float* dres,
                          long long lddres, int write_f32, void* gout_bf16, long long ldgout, void* gout_fp8,
                          long long ldd8, float* scale_inv, int accumulate, float* dgamma, float* dbeta, float* colsum,

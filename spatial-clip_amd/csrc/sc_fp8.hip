@@ -116,7 +116,7 @@ extern "C" int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long l
 
 static int gemm_fp8_impl(int epi, const void* A8, int lda, const float* a_scale_inv, int a_scale_scalar, const void* B8, int ldb,
                          const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
-                         const float* bias, const float* res, int ldres, const void* aux, int ldaux, void* q8_out,
+                         const float* bias, const void* res, int ldres, const void* aux, int ldaux, void* q8_out,
                          long long ldq8, const float* q8_scale, float* q8_amax, void* stream) {
     SC_CHECK(M > 0 && N > 0 && K > 0 && (K % 128) == 0, "sc_gemm_fp8: K (%d) must be a positive multiple of 128", K);
     SC_CHECK((lda % 16) == 0 && (ldb % 16) == 0 && ((uintptr_t)A8 % 16) == 0 && ((uintptr_t)B8 % 16) == 0,
@@ -126,7 +126,7 @@ static int gemm_fp8_impl(int epi, const void* A8, int lda, const float* a_scale_
     SC_CHECK((N % (f32out ? 4 : 8)) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0, "sc_gemm_fp8: N=%d ldc=%d", N, ldc);
     GemmArgs g;
     g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
-    g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
+    g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = (const float*)res; g.ldres = ldres;
     g.aux = (const bf16*)aux; g.ldaux = ldaux; g.colsum = nullptr; g.tile_offset = 0;
     g.a_scale = a_scale_inv; g.b_scale = b_scale_inv; g.a_scale_scalar = a_scale_scalar;
     if (q8_out != nullptr) {
@@ -142,14 +142,14 @@ static int gemm_fp8_impl(int epi, const void* A8, int lda, const float* a_scale_
 
 extern "C" int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
                            const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
-                           const float* bias, const float* res, int ldres, const void* aux, int ldaux, void* stream) {
+                           const float* bias, const void* res, int ldres, const void* aux, int ldaux, void* stream) {
     return gemm_fp8_impl(epi, A8, lda, a_scale_inv, 0, B8, ldb, b_scale_inv, M, N, K, C, ldc, C2, ldc2, bias, res, ldres, aux,
                          ldaux, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int sc_gemm_fp8_q(int epi, const void* A8, int lda, const float* a_scale_inv, int a_scale_scalar, const void* B8,
                              int ldb, const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
-                             const float* bias, const float* res, int ldres, const void* aux, int ldaux, void* q8_out,
+                             const float* bias, const void* res, int ldres, const void* aux, int ldaux, void* q8_out,
                              long long ldq8, const float* q8_scale, float* q8_amax, void* stream) {
     return gemm_fp8_impl(epi, A8, lda, a_scale_inv, a_scale_scalar, B8, ldb, b_scale_inv, M, N, K, C, ldc, C2, ldc2, bias, res,
                          ldres, aux, ldaux, q8_out, ldq8, q8_scale, q8_amax, stream);

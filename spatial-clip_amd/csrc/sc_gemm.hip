@@ -208,7 +208,7 @@ int launch(const GemmArgs& g, int nblocks, hipStream_t st) {
 }  // namespace
 
 extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
-                            void* C, int ldc, void* C2, int ldc2, const float* bias, const float* res, int ldres,
+                            void* C, int ldc, void* C2, int ldc2, const float* bias, const void* res, int ldres,
                             const void* aux, int ldaux, int splitk, float* slabs, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     SC_CHECK(mode == SC_GEMM_NT || mode == SC_GEMM_TN, "sc_gemm_bf16: bad mode %d", mode);
@@ -224,7 +224,7 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     SC_CHECK(splitk == 1 || (epi == SC_EPI_F32 && slabs != nullptr), "sc_gemm_bf16: split-K needs EPI_F32 + slabs");
     GemmArgs g;
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
-    g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
+    g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = (const float*)res; g.ldres = ldres;
     g.aux = (const bf16*)aux; g.ldaux = ldaux;
     g.colsum = nullptr; g.tile_offset = 0;
     // kernel choice: 256x256 phase-interleaved kernel (NT) -> 256x256 two-stage LDS-DMA kernel (TN, and NT when
@@ -269,6 +269,7 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     SC_CASE(SC_GEMM_NT, SC_EPI_F32_BIAS_RES)
     SC_CASE(SC_GEMM_NT, SC_EPI_GELU_PAIR)
     SC_CASE(SC_GEMM_NT, SC_EPI_BF16_DGELU)
+    SC_CASE(SC_GEMM_NT, SC_EPI_BF16_BIAS_RES)
     SC_CASE(SC_GEMM_NT, SC_EPI_F32)
     SC_CASE(SC_GEMM_TN, SC_EPI_F32)
     SC_CASE(SC_GEMM_TN, SC_EPI_BF16)

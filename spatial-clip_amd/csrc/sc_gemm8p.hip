@@ -953,6 +953,7 @@ int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st) {
     if (epi == SC_EPI_GELU_PAIR) return launch_f8<SC_EPI_GELU_PAIR>(g, nblocks, st);
     if (epi == SC_EPI_BF16_DGELU) return launch_f8<SC_EPI_BF16_DGELU>(g, nblocks, st);
     if (epi == SC_EPI_F32) return launch_f8<SC_EPI_F32>(g, nblocks, st);
+    if (epi == SC_EPI_BF16_BIAS_RES) return launch_f8<SC_EPI_BF16_BIAS_RES>(g, nblocks, st);
     return 0;
 }
 
@@ -996,6 +997,7 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     SC_CASE(SC_EPI_GELU_PAIR)
     SC_CASE(SC_EPI_BF16_DGELU)
     SC_CASE(SC_EPI_F32)
+    SC_CASE(SC_EPI_BF16_BIAS_RES)
 #undef SC_CASE
     return rc;
 }

@@ -102,7 +102,7 @@ SC_DEVICE void sc_epi_put(float* ep, int row16, int col16, int li, int lg, f32x4
 template <int EPI>
 struct EpiRegs {
     static constexpr bool kRes = (EPI == SC_EPI_F32_BIAS_RES);
-    static constexpr bool kAux = (EPI == SC_EPI_BF16_DGELU);
+    static constexpr bool kAux = (EPI == SC_EPI_BF16_DGELU || EPI == SC_EPI_BF16_BIAS_RES);    // a bf16 input tile
     f32x4 r[kRes ? 16 : 1];
     bf16x8 a[kAux ? 8 : 1];
 };
@@ -126,6 +126,17 @@ SC_DEVICE void sc_epi_load(EpiRegs<EPI>& e, int gm0, int gn0, int lane, const Ge
         for (int ps = 0; ps < 8; ++ps) {
             const int gm = gm0 + ps * 8 + (lane >> 3);
             if (gm < mlim && gn < g.N) e.a[ps] = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm * g.ldaux + gn);
+        }
+    }
+    if (EPI == SC_EPI_BF16_BIAS_RES) {            // the residual stream in bf16: g.res points at bf16 data, ldres in elements
+        const int gn = gn0 + (lane & 7) * 8;
+        const bf16* res = reinterpret_cast<const bf16*>(g.res);
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int gm = gm0 + ps * 8 + (lane >> 3);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e.a[ps][k] = (bf16)0.0f;
+            if (res && gm < mlim && gn < g.N) e.a[ps] = *reinterpret_cast<const bf16x8*>(res + (size_t)gm * g.ldres + gn);
         }
     }
 }
@@ -166,7 +177,7 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
         float bv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) bv[k] = 0.f;
-        if ((EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) && g.bias && gn < g.N) {
+        if ((EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR || EPI == SC_EPI_BF16_BIAS_RES) && g.bias && gn < g.N) {
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + gn);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias + gn + 4);
 #pragma unroll
@@ -188,6 +199,18 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
                     const int gm2 = next_gm0 + row;
                     if (gm2 < g.M && gn < g.N)
                         e.a[ps] = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)gm2 * g.ldaux + gn);
+                }
+            }
+            if (EPI == SC_EPI_BF16_BIAS_RES) {      // x_new = bf16(acc + bias + x): one rounding, from the fp32 staging tile
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += (float)e.a[ps][k];
+                if (next_gm0 >= 0) {
+                    const int gm2 = next_gm0 + row;
+                    const bf16* res = reinterpret_cast<const bf16*>(g.res);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e.a[ps][k] = (bf16)0.0f;
+                    if (res && gm2 < g.M && gn < g.N)
+                        e.a[ps] = *reinterpret_cast<const bf16x8*>(res + (size_t)gm2 * g.ldres + gn);
                 }
             }
             if (gm < mlim && gn < g.N) {

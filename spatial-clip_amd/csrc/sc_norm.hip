@@ -35,7 +35,8 @@ SC_DEVICE float ln_row_scale(float amax_lane) {
     return amax > 0.f ? exp2f(floorf(log2f(448.0f / amax))) : 1.0f;
 }
 
-template <int NV, bool Q8>
+// XB: the input rows are bf16 (the residual stream kept in bf16, SC_EPI_BF16_BIAS_RES); x then points at bf16 data
+template <int NV, bool Q8, bool XB = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      bf16* __restrict__ y, long long ldy, float* __restrict__ mean,
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int row = rows - 1 - (blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row < 0) return;
     const float* xr = x + (long long)row * ldx;
+    const bf16* xrb = reinterpret_cast<const bf16*>(x) + (long long)row * ldx;
     const int nv = d >> 2;
     f32x4 v[NV];
     float s = 0.f;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = 0; i < NV; ++i) {
         const int e = i * 64 + lane;
         if (e < nv) {
-            v[i] = ld4(xr + e * 4);
+            v[i] = XB ? ldbf4(xrb + e * 4) : ld4(xr + e * 4);
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
     }
@@ -108,11 +110,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ------------------------------------------------------------------ LayerNorm backward
 // dres_new = (accumulate ? dres : 0) + LNbwd(dy) (accumulate = -P: dres only holds rows r % P == 0); also emits the bf16 copy of dres_new (the A operand of
 // the next dgrad / wgrad GEMMs) and per-block partials of dgamma, dbeta and colsum(dres_new).
-// G16: the residual gradient travels in bf16 (the reference's own precision for it: under its bf16 autocast the residual
+// gin != nullptr: the residual gradient travels in bf16 (the reference's own precision for it: under its bf16 autocast the residual
 // stream and therefore its gradient are bf16 tensors): the incoming gradient is read from ``gin`` (bf16) instead of the fp32
 // ``dres``, and ``dres`` is written only when ``write_f32`` asks for it (the last hop in front of the stem) -- 10 instead of
 // 16 bytes per element cross HBM.  The sparse form (accumulate = -P) still reads its few class-token rows from ``dres``.
-template <int NV, bool Q8, bool G16 = false>
+template <int NV, bool Q8, bool XB = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         const float mu = mean[row], rs = rstd[row];
         const bf16* dyr = dy + (long long)row * lddy;
         const float* xr = x + (long long)row * ldx;
+        const bf16* xrb = reinterpret_cast<const bf16*>(x) + (long long)row * ldx;
         f32x4 g[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             const int e = i * 64 + lane;
             if (e < nv) {
                 const f32x4 dyv = ldbf4(dyr + e * 4);
-                const f32x4 xv = ld4(xr + e * 4);
+                const f32x4 xv = XB ? ldbf4(xrb + e * 4) : ld4(xr + e * 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     xh[i][c] = (xv[c] - mu) * rs;
@@ -169,13 +172,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             const int e = i * 64 + lane;
             if (e < nv) {
                 f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (acc_row) o = (G16 && accumulate > 0) ? ldbf4(gin + (long long)row * ldgin + e * 4) : ld4(dr + e * 4);
+                if (acc_row) o = (gin != nullptr && accumulate > 0) ? ldbf4(gin + (long long)row * ldgin + e * 4) : ld4(dr + e * 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     o[c] += rs * (g[i][c] - s1 - xh[i][c] * s2);
                     ac[i][c] += o[c];
                 }
-                if (!G16 || write_f32) st4(dr + e * 4, o);
+                if (write_f32) st4(dr + e * 4, o);
                 if (db) stbf4(db + e * 4, o);
                 if (Q8) {
                     g[i] = o;
@@ -482,7 +485,7 @@ extern "C" int sc_cast_transpose_batched(const float* master, const void* mirror
 
 static int ln_fwd_launch(const float* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
                          float* mean, float* rstd, int rows, int d, float eps, void* y8, long long ldy8, float* scale_inv,
-                         void* stream) {
+                         void* stream, bool xb = false) {
     SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_fwd: bad shape rows=%d d=%d", rows, d);
     SC_CHECK((ldx % 4) == 0 && (ldy % 4) == 0, "sc_layernorm_fwd: row strides must be multiples of 4");
     SC_CHECK(y8 == nullptr || (scale_inv != nullptr && (ldy8 % 4) == 0 && ldy8 >= d),
@@ -490,7 +493,12 @@ static int ln_fwd_launch(const float* x, long long ldx, const float* gamma, cons
     const int nvv = (d / 4 + 63) / 64;
 #define SC_LN_FWD(NV)                                                                                                     \
     do {                                                                                                                  \
-        if (y8) ln_fwd_kernel<NV, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                                 \
+        if (xb) {                                                                                                         \
+            if (y8) ln_fwd_kernel<NV, true, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                       \
+                x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, (unsigned char*)y8, ldy8, scale_inv);       \
+            else ln_fwd_kernel<NV, false, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                         \
+                x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, nullptr, 0, nullptr);                       \
+        } else if (y8) ln_fwd_kernel<NV, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                          \
             x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, (unsigned char*)y8, ldy8, scale_inv);           \
         else ln_fwd_kernel<NV, false><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                                   \
             x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, nullptr, 0, nullptr);                           \
@@ -514,6 +522,14 @@ extern "C" int sc_layernorm_fwd_q8(const float* x, long long ldx, const float* g
     return ln_fwd_launch(x, ldx, gamma, beta, y, ldy, mean, rstd, rows, d, eps, y_fp8, ldy8, scale_inv, stream);
 }
 
+extern "C" int sc_layernorm_fwd_x16(const void* x_bf16, long long ldx, const float* gamma, const float* beta, void* y,
+                                    long long ldy, void* y_fp8, long long ldy8, float* scale_inv, float* mean, float* rstd,
+                                    int rows, int d, float eps, void* stream) {
+    SC_CHECK(x_bf16 != nullptr, "sc_layernorm_fwd_x16: input required");
+    return ln_fwd_launch((const float*)x_bf16, ldx, gamma, beta, y, ldy, mean, rstd, rows, d, eps, y_fp8, ldy8, scale_inv, stream,
+                         true);
+}
+
 extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
     int nblk = (rows + 3) / 4;
     if (nblk > 1024) nblk = 1024;
@@ -523,8 +539,8 @@ extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
 static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
                          const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
                          long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum, float* ws, int rows,
-                         int d, void* d8, long long ldd8, float* scale_inv, void* stream, bool g16 = false,
-                         const void* gin = nullptr, long long ldgin = 0, int write_f32 = 1) {
+                         int d, void* d8, long long ldd8, float* scale_inv, void* stream,
+                         const void* gin = nullptr, long long ldgin = 0, int write_f32 = 1, bool xb = false) {
     SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_bwd: bad shape rows=%d d=%d", rows, d);
     SC_CHECK(ws != nullptr, "sc_layernorm_bwd: workspace required");
     SC_CHECK(d8 == nullptr || (scale_inv != nullptr && (ldd8 % 4) == 0 && ldd8 >= d),
@@ -546,7 +562,7 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
     } while (0)
 #define SC_LN_BWD(NV)                                                                                                   \
     do {                                                                                                                \
-        if (g16) { if (d8) SC_LN_BWD_Q(NV, true, true); else SC_LN_BWD_Q(NV, false, true); }                            \
+        if (xb) { if (d8) SC_LN_BWD_Q(NV, true, true); else SC_LN_BWD_Q(NV, false, true); }                             \
         else { if (d8) SC_LN_BWD_Q(NV, true, false); else SC_LN_BWD_Q(NV, false, false); }                              \
     } while (0)
     if (nvv <= 1) SC_LN_BWD(1); else if (nvv == 2) SC_LN_BWD(2); else if (nvv == 3) SC_LN_BWD(3);
@@ -586,7 +602,19 @@ extern "C" int sc_layernorm_bwd_g16(const void* dy, long long lddy, const float*
     SC_CHECK(accumulate <= 0 || (gin_bf16 != nullptr && (ldgin % 4) == 0), "sc_layernorm_bwd_g16: bf16 input gradient required");
     SC_CHECK((accumulate >= 0 && !write_f32) || dres != nullptr, "sc_layernorm_bwd_g16: fp32 buffer required (sparse input or fp32 output)");
     return ln_bwd_launch(dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, gout_bf16, ldgout, accumulate, dgamma, dbeta,
-                         colsum, ws, rows, d, gout_fp8, ldd8, scale_inv, stream, true, gin_bf16, ldgin, write_f32);
+                         colsum, ws, rows, d, gout_fp8, ldd8, scale_inv, stream, gin_bf16, ldgin, write_f32);
+}
+
+extern "C" int sc_layernorm_bwd_x16(const void* dy, long long lddy, const void* x_bf16, long long ldx, const float* mean,
+                                    const float* rstd, const float* gamma, const void* gin_bf16, long long ldgin,
+                                    float* dres, long long lddres, int write_f32, void* gout_bf16, long long ldgout,
+                                    void* gout_fp8, long long ldd8, float* scale_inv, int accumulate, float* dgamma,
+                                    float* dbeta, float* colsum, float* ws, int rows, int d, void* stream) {
+    SC_CHECK(x_bf16 != nullptr && (ldx % 4) == 0, "sc_layernorm_bwd_x16: bf16 input rows with a stride that is a multiple of 4");
+    SC_CHECK((accumulate == 0 && !write_f32) || gin_bf16 != nullptr || dres != nullptr,
+             "sc_layernorm_bwd_x16: an incoming gradient or an fp32 output needs its buffer");
+    return ln_bwd_launch(dy, lddy, (const float*)x_bf16, ldx, mean, rstd, gamma, dres, lddres, gout_bf16, ldgout, accumulate,
+                         dgamma, dbeta, colsum, ws, rows, d, gout_fp8, ldd8, scale_inv, stream, gin_bf16, ldgin, write_f32, true);
 }
 
 extern "C" int sc_layernorm_bwd_reduce(const float* ws, int rows, int d, float* dgamma, float* dbeta, float* colsum,

@@ -133,7 +133,8 @@ class SpatialClipNet(torch.nn.Module):
     def __init__(self, model_name: str, pretrained: Optional[str] = None, aug_cfg: Optional[Any] = None,
                  cache_dir: Optional[str] = None, n_genes: Optional[int] = None, gene_hidden: Optional[int] = None,
                  device: Optional[str] = None, seed: int = 0, model_cfg: Optional[ModelCfg] = None,
-                 tokenizer_vocab: Optional[str] = None, precision: str = "bf16", grad_checkpointing: bool = False):
+                 tokenizer_vocab: Optional[str] = None, precision: str = "bf16", grad_checkpointing: bool = False,
+                 residual_stream: str = "fp32"):
         super().__init__()
         if aug_cfg is not None and not isinstance(aug_cfg, (dict, AugmentationCfg)) and not is_dataclass(aug_cfg) \
                 and not hasattr(aug_cfg, "items"):
@@ -171,6 +172,16 @@ class SpatialClipNet(torch.nn.Module):
             self._load_pretrained(pretrained)
         if grad_checkpointing:              # config key model.net.grad_checkpointing (open_clip: --grad-checkpointing)
             self.set_grad_checkpointing(True)
+        # config key model.net.residual_stream: "fp32" (default: the forward residual stream x + attn(..) + mlp(..) in fp32,
+        # better than the reference) or "bf16" (what the reference's bf16 autocast keeps: -1.7 % step time, 2.3x the feature
+        # noise against the fp32 oracle -- DESIGN.md section 7); the patch towers only
+        if residual_stream not in ("fp32", "bf16"):
+            raise ValueError(f"residual_stream {residual_stream!r}: 'fp32' or 'bf16'")
+        self.residual_stream = residual_stream
+        for tower in (self.vision, self.second):
+            stack = getattr(tower, "stack", None)
+            if stack is not None:
+                stack.res_stream = residual_stream
 
     # ------------------------------------------------------------------ reference-facing helpers
     def set_grad_checkpointing(self, enable: bool = True) -> None:

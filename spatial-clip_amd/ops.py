@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import check
 
 NT, TN = 0, 1
-EPI_BF16, EPI_BF16_BIAS, EPI_F32_BIAS_RES, EPI_GELU_PAIR, EPI_BF16_DGELU, EPI_F32 = range(6)
+EPI_BF16, EPI_BF16_BIAS, EPI_F32_BIAS_RES, EPI_GELU_PAIR, EPI_BF16_DGELU, EPI_F32, EPI_BF16_BIAS_RES = range(7)
 
 
 def _stream() -> int:
@@ -51,7 +51,7 @@ def gemm(mode: int, epi: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tenso
     want = torch.float32 if epi in (EPI_F32, EPI_F32_BIAS_RES) else torch.bfloat16
     _req(out, want, "out")
     if bias is not None: _req(bias, torch.float32, "bias")
-    if res is not None: _req(res, torch.float32, "res")
+    if res is not None: _req(res, torch.bfloat16 if epi == EPI_BF16_BIAS_RES else torch.float32, "res")
     if aux is not None: _req(aux, torch.bfloat16, "aux")
     if out2 is not None: _req(out2, torch.bfloat16, "out2")
     l = _lib.lib()
@@ -144,11 +144,20 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows: int, d: int, ldx: Optiona
                   q8_scale_inv: Optional[torch.Tensor] = None):
     """``q8`` (uint8 [rows, d]) + ``q8_scale_inv`` (fp32 [rows]): also emit the e4m3 copy of the output with its
     per-row power-of-two scale (the fp8 forward GEMM's A operand) from the same kernel."""
-    _req(x, torch.float32, "x"); _req(y, torch.bfloat16, "y")
+    _req(y, torch.bfloat16, "y")
     if q8 is not None:
         if q8.dtype != torch.uint8 or not q8.is_cuda or q8.stride(-1) != 1:
             raise TypeError("layernorm_fwd: q8 must be a device uint8 matrix")
         _req(q8_scale_inv, torch.float32, "q8_scale_inv")
+    if x.dtype == torch.bfloat16:           # residual stream kept in bf16 (EPI_BF16_BIAS_RES)
+        _req(x, torch.bfloat16, "x")
+        check(_lib.lib().sc_layernorm_fwd_x16(x.data_ptr(), ldx if ldx is not None else d, gamma.data_ptr(), beta.data_ptr(),
+                                              y.data_ptr(), ldy if ldy is not None else d, _ptr(q8),
+                                              q8.stride(0) if q8 is not None else 0, _ptr(q8_scale_inv), _ptr(mean),
+                                              _ptr(rstd), rows, d, eps, _stream()), "sc_layernorm_fwd_x16")
+        return y
+    _req(x, torch.float32, "x")
+    if q8 is not None:
         check(_lib.lib().sc_layernorm_fwd_q8(x.data_ptr(), ldx if ldx is not None else d, gamma.data_ptr(),
                                              beta.data_ptr(), y.data_ptr(), ldy if ldy is not None else d, q8.data_ptr(),
                                              q8.stride(0), q8_scale_inv.data_ptr(), _ptr(mean), _ptr(rstd), rows, d, eps,
@@ -178,24 +187,31 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, cols
     layernorm_bwd_ws_floats floats) and finish them with layernorm_bwd_reduce -- e.g. on the weight-gradient stream.
     ``g16`` (sc_layernorm_bwd_g16): the residual gradient travels in bf16 -- the incoming one is ``g_in`` (bf16) when
     ``accumulate`` is True, the outgoing one ``dres_bf16``; the fp32 ``dres`` is written only if ``write_f32``."""
-    _req(dy, torch.bfloat16, "dy"); _req(x, torch.float32, "x"); _req(dres, torch.float32, "dres")
+    _req(dy, torch.bfloat16, "dy"); _req(dres, torch.float32, "dres")
+    xb = x.dtype == torch.bfloat16          # residual stream kept in bf16
+    _req(x, torch.bfloat16 if xb else torch.float32, "x")
     l = _lib.lib()
     if ws is None:
         if defer_reduce:
             raise _lib.SpatialClipHipError("layernorm_bwd: defer_reduce needs a caller-owned workspace")
         ws = workspace(l.sc_layernorm_bwd_ws_floats(rows, d), dy.device, "ln")
+    legacy = xb and not g16                 # bf16 rows, fp32 gradient buffer read-modify-written as in sc_layernorm_bwd
+    if legacy:
+        g16, g_in, write_f32 = True, None, True
     if g16:
-        if int(accumulate) > 0:
+        if int(accumulate) > 0 and not legacy:
             _req(g_in, torch.bfloat16, "g_in")
-        _req(dres_bf16, torch.bfloat16, "dres_bf16")
+        if dres_bf16 is not None or not legacy:
+            _req(dres_bf16, torch.bfloat16, "dres_bf16")
         if q8 is not None:
             _req(q8_scale_inv, torch.float32, "q8_scale_inv")
-        check(l.sc_layernorm_bwd_g16(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
+        fn = l.sc_layernorm_bwd_x16 if xb else l.sc_layernorm_bwd_g16
+        check(fn(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
                                      gamma.data_ptr(), _ptr(g_in), ldgin or d, dres.data_ptr(), lddres or d, int(write_f32),
-                                     dres_bf16.data_ptr(), lddbf or d, _ptr(q8), q8.stride(0) if q8 is not None else 0,
+                                     _ptr(dres_bf16), lddbf or d, _ptr(q8), q8.stride(0) if q8 is not None else 0,
                                      _ptr(q8_scale_inv), int(accumulate),
                                      None if defer_reduce else dgamma.data_ptr(), dbeta.data_ptr(), _ptr(colsum),
-                                     ws.data_ptr(), rows, d, _stream()), "sc_layernorm_bwd_g16")
+                                     ws.data_ptr(), rows, d, _stream()), "sc_layernorm_bwd_x16" if xb else "sc_layernorm_bwd_g16")
         return
     if q8 is not None:          # e4m3 copy of the new residual gradient + per-row 1/scale (A operand of the fp8 dgrad GEMMs)
         if q8.dtype != torch.uint8 or not q8.is_cuda or q8.stride(-1) != 1:
@@ -536,6 +552,7 @@ def gemm_fp8(epi: int, a8: torch.Tensor, a_scale_inv: torch.Tensor, b8: torch.Te
     _req(a_scale_inv, torch.float32, "a_scale_inv"); _req(b_scale_inv, torch.float32, "b_scale_inv")
     want = torch.float32 if epi in (EPI_F32, EPI_F32_BIAS_RES) else torch.bfloat16
     _req(out, want, "out")
+    if res is not None: _req(res, torch.bfloat16 if epi == EPI_BF16_BIAS_RES else torch.float32, "res")
     ev = None
     if KERNEL_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

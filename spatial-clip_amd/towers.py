@@ -54,7 +54,7 @@ class TransformerStack:
     """N pre-LN residual attention blocks (ResidualAttentionBlock, transformer.py:238-300)."""
 
     def __init__(self, store: ParamStore, prefix: str, width: int, heads: int, layers: int, mlp: int, causal: bool,
-                 cls_only_last: bool = False):
+                 cls_only_last: bool = False, res16_ok: bool = False):
         # cls_only_last: only token 0 of the last block's output is consumed downstream (ViT pool 'tok'), so that
         # block computes K/V for all tokens but attention output, out_proj and the MLP for the CLS rows only -- the
         # values the reference would compute for the other 196 rows are dead.
@@ -64,6 +64,11 @@ class TransformerStack:
         self.dh = width // heads
         self.bufs = _Bufs(store.device)
         self.fp8 = bool(getattr(store, "fp8", False))
+        # residual stream in bf16 (what the reference's autocast keeps; SC_RES_STREAM, read at every forward) for the towers
+        # whose stem / head kernels take it (the patch towers); off: fp32 stream
+        self.res16_ok = res16_ok
+        self.res_stream = "fp32"
+        self.r16 = False
         # activation recomputation (set_grad_checkpointing): the LayerNorm outputs and the GELU output of a block are not
         # kept for the backward (12 of the 36 d bytes a token saves per block); the backward rebuilds them, bit-identically,
         # from the saved residual stream / pre-activation right before the weight-gradient GEMMs that read them
@@ -127,7 +132,12 @@ class TransformerStack:
         M = B * L
         self.B, self.L, self.M = B, L, M
         bf = self.bufs
+        self.r16 = r16 = self.res16_ok and _res_stream_bf16(self.res_stream)
+        XD = BF16 if r16 else F32                     # dtype of the residual stream between the blocks
+        epi_res = ops.EPI_BF16_BIAS_RES if r16 else ops.EPI_F32_BIAS_RES
         x = x0
+        if r16:                                       # the stem writes fp32: one cast pass per step
+            x = ops.cast_pad_bf16(x0, bf.get("x0.16", (M, d), BF16), M, d, d)
         self.x_in = [None] * self.layers
         for i in range(self.layers):
             self.x_in[i] = x
@@ -145,8 +155,8 @@ class TransformerStack:
             if self.cls_only_last and i == self.layers - 1:
                 return self._forward_last_cls(i, x, qkv, o, lse)
             ops.attn_fwd(qkv, B, L, H, dh, self.causal, out=o, lse=lse)
-            xmid = bf.get(f"xmid.{i}", (M, d), F32)
-            self._linear_fwd(ops.EPI_F32_BIAS_RES, o, self._n(i, "attn.out_proj.weight"), xmid,
+            xmid = bf.get(f"xmid.{i}", (M, d), XD)
+            self._linear_fwd(epi_res, o, self._n(i, "attn.out_proj.weight"), xmid,
                              M=M, N=d, K=d, bias=s.p(self._n(i, "attn.out_proj.bias")), res=x)
             a2 = self._act("a2", i, (M, d))
             m2 = bf.get(f"m2.{i}", (M,), F32)
@@ -161,13 +171,13 @@ class TransformerStack:
                 hq = dict(q8_out=h8, q8_scale=self._dq_scale[2 * i:2 * i + 1], q8_amax=self._dq_amax[2 * i])
             self._linear_fwd(ops.EPI_GELU_PAIR, a2, self._n(i, "mlp.c_fc.weight"), u,
                              M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h, q8=qa, **(hq or {}))
-            xo = bf.get(f"xout.{i}", (M, d), F32)
+            xo = bf.get(f"xout.{i}", (M, d), XD)
             cpj = s.copies[self._n(i, "mlp.c_proj.weight")]
             if hq is not None and self._dq_ready and cpj.w8 is not None:
-                ops.gemm_fp8(ops.EPI_F32_BIAS_RES, h8, self._dq_scale_inv[2 * i:2 * i + 1], cpj.w8, cpj.w8s, xo, M=M, N=d,
+                ops.gemm_fp8(epi_res, h8, self._dq_scale_inv[2 * i:2 * i + 1], cpj.w8, cpj.w8s, xo, M=M, N=d,
                              K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid, a_scale_scalar=True)
             else:
-                self._linear_fwd(ops.EPI_F32_BIAS_RES, h, self._n(i, "mlp.c_proj.weight"), xo,
+                self._linear_fwd(epi_res, h, self._n(i, "mlp.c_proj.weight"), xo,
                                  M=M, N=d, K=mlp, bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
             x = xo
         return x
@@ -179,8 +189,10 @@ class TransformerStack:
         ops.attn_fwd(qkv, B, L, H, dh, self.causal, out=o, lse=lse, q_rows=1)
         o_c = o.view(B, L * d)[:, :d]
         x_c = x.view(B, L * d)[:, :d]
-        xmid = bf.get("c.xmid", (B, d), F32)
-        ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, o_c, s.copies[self._n(i, "attn.out_proj.weight")].wf, xmid,
+        XD = BF16 if self.r16 else F32
+        epi_res = ops.EPI_BF16_BIAS_RES if self.r16 else ops.EPI_F32_BIAS_RES
+        xmid = bf.get("c.xmid", (B, d), XD)
+        ops.gemm(ops.NT, epi_res, o_c, s.copies[self._n(i, "attn.out_proj.weight")].wf, xmid,
                  M=B, N=d, K=d, bias=s.p(self._n(i, "attn.out_proj.bias")), res=x_c)
         a2 = bf.get("c.a2", (B, d), BF16)
         ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
@@ -188,8 +200,8 @@ class TransformerStack:
         u, h = bf.get("c.u", (B, mlp), BF16), bf.get("c.h", (B, mlp), BF16)
         ops.gemm(ops.NT, ops.EPI_GELU_PAIR, a2, s.copies[self._n(i, "mlp.c_fc.weight")].wf, u, M=B, N=mlp, K=d,
                  bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)
-        xo = bf.get("c.xout", (B, d), F32)
-        ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, h, s.copies[self._n(i, "mlp.c_proj.weight")].wf, xo, M=B, N=d, K=mlp,
+        xo = bf.get("c.xout", (B, d), XD)
+        ops.gemm(ops.NT, epi_res, h, s.copies[self._n(i, "mlp.c_proj.weight")].wf, xo, M=B, N=d, K=mlp,
                  bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
         return xo
 
@@ -205,7 +217,7 @@ class TransformerStack:
         a1, qkv, o = bf.get(f"a1.{i}", (M, d), BF16), bf.get(f"qkv.{i}", (M, 3 * d), BF16), bf.get(f"o.{i}", (M, d), BF16)
         lse = bf.get(f"lse.{i}", (B, H, L), F32)
         a2, u, h, xmid = bf.get("c.a2", (B, d), BF16), bf.get("c.u", (B, mlp), BF16), bf.get("c.h", (B, mlp), BF16), \
-            bf.get("c.xmid", (B, d), F32)
+            bf.get("c.xmid", (B, d), BF16 if self.r16 else F32)
         dU = bf.get("c.dU", (B, mlp), BF16)
         dA_c = bf.get("c.dA", (B, d), BF16)
         dres_c_bf_ = dres_c_bf
@@ -351,7 +363,7 @@ class TransformerStack:
             cp = lambda leaf, i=i: s.copies[self._n(i, leaf)]
             a1, qkv, o = self._act("a1", i, (M, d)), bf.get(f"qkv.{i}", (M, 3 * d), BF16), bf.get(f"o.{i}", (M, d), BF16)
             a2, u, h = self._act("a2", i, (M, d)), bf.get(f"u.{i}", (M, mlp), BF16), self._act("h", i, (M, mlp))
-            xmid = bf.get(f"xmid.{i}", (M, d), F32)
+            xmid = bf.get(f"xmid.{i}", (M, d), BF16 if self.r16 else F32)
             lse = bf.get(f"lse.{i}", (B, H, L), F32)
             dU = bf.get(f"dU.{i & 1}", (M, mlp), BF16)
             dqkv = bf.get(f"dqkv.{i & 1}", (M, 3 * d), BF16)
@@ -424,6 +436,12 @@ class TransformerStack:
             main.wait_event(ev)
         return dres
 
+def _res_stream_bf16(configured: str = "fp32") -> bool:
+    """Read at every forward: the residual stream of the patch towers in bf16 (the reference's precision under its bf16
+    autocast) or fp32 (default) -- SpatialClipNet(residual_stream=...), overridden by SC_RES_STREAM=bf16|fp32 for A/B."""
+    return os.environ.get("SC_RES_STREAM", configured) == "bf16"
+
+
 def _res_grad_bf16() -> bool:
     """Read at every backward: SC_RES_GRAD=fp32 restores the fp32 residual-gradient buffer (A/B, tests)."""
     return os.environ.get("SC_RES_GRAD", "bf16") != "fp32"
@@ -446,7 +464,7 @@ class PatchTransformerTower:
         self.kp = patch_dim
         self.kp_pad = store.copies[self.prefix + "conv1.weight"].k_pad
         self.stack = TransformerStack(store, self.prefix + "transformer.resblocks.", width, heads, layers,
-                                      int(width * mlp_ratio), causal=False, cls_only_last=True)
+                                      int(width * mlp_ratio), causal=False, cls_only_last=True, res16_ok=True)
         self.bufs = _Bufs(store.device)
 
     def _n(self, leaf: str) -> str:

@@ -117,8 +117,6 @@ def test_vitb16_b256_loss_within_1e3_of_fp32_oracle(which):
                                      neighbor_alpha_scale=0.5, float32_logits=True)
     n, m = _module(net, module, losses, optim, loss_fn, seed=0)
     with torch.no_grad():
-        out = m.model_step({k: v.cuda() for k, v in batch.items()})
-        torch.cuda.synchronize()
         v = n.cfg.vision
         ocfg = O.ModelCfg(n.cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
                           O.GeneCfg(n.cfg.gene.n_genes, n.cfg.gene.hidden))
@@ -130,15 +128,23 @@ def test_vitb16_b256_loss_within_1e3_of_fp32_oracle(which):
         else:
             ref = O.spatial_loss(f["image_features"], f["text_features"], f["logit_scale"], batch["image_tile_ids"],
                                  batch["text_tile_ids"], batch["neighbor_tile_ids"], batch["neighbor_alphas"])
-    dl = abs(float(out["loss"]) - float(ref))
-    df = max(float((out["image_features"].cpu() - f["image_features"]).abs().max()),
-             float((out["text_features"].cpu() - f["text_features"]).abs().max()))
-    print(f"[fullsize {which}] loss {float(out['loss']):.6f} vs oracle {float(ref):.6f}: |d|={dl:.2e}, max|d feature|={df:.2e}")
-    assert dl <= 1e-3, dl
-    assert df <= 5e-3, df
-    assert out["logits"].shape == (B, B)                   # model_step's output contract (spatial_clip_module.py:66-70)
-    torch.testing.assert_close(out["logits"].cpu(), (f["image_features"] @ f["text_features"].t()) * f["logit_scale"],
-                               atol=14.3 * 5e-3 * 2, rtol=0)
+    # the same bound with the forward residual stream in fp32 (default) and in bf16 (model.net.residual_stream=bf16: the
+    # precision the reference's autocast keeps it in)
+    for stream in ("fp32", "bf16"):
+        n.vision.stack.res_stream = stream
+        with torch.no_grad():
+            out = m.model_step({k: v.cuda() for k, v in batch.items()})
+            torch.cuda.synchronize()
+        dl = abs(float(out["loss"]) - float(ref))
+        df = max(float((out["image_features"].cpu() - f["image_features"]).abs().max()),
+                 float((out["text_features"].cpu() - f["text_features"]).abs().max()))
+        print(f"[fullsize {which}, residual stream {stream}] loss {float(out['loss']):.6f} vs oracle {float(ref):.6f}: "
+              f"|d|={dl:.2e}, max|d feature|={df:.2e}")
+        assert dl <= 1e-3, (stream, dl)
+        assert df <= 5e-3, (stream, df)
+        assert out["logits"].shape == (B, B)               # model_step's output contract (spatial_clip_module.py:66-70)
+        torch.testing.assert_close(out["logits"].cpu(), (f["image_features"] @ f["text_features"].t()) * f["logit_scale"],
+                                   atol=14.3 * 5e-3 * 2, rtol=0)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -131,6 +131,28 @@ def test_nt_residual_gelu_dgelu(M, N, K):
     torch.testing.assert_close(d.float().cpu(), (ref * x.grad).to(torch.bfloat16).float(), atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(333, 192, 256), (197 * 4, 768, 192), (700, 264, 64), (197 * 64, 768, 768), (64, 768, 3072)])
+def test_nt_bf16_residual_epilogue(M, N, K):
+    """SC_EPI_BF16_BIAS_RES: x_new = bf16(A.B^T + bias + x) with the residual x read as bf16 (strided rows included, as the
+    class-token-only block passes them): equal to the fp32-residual epilogue fed with float(x), rounded once."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    a, b = _rand((M, K), g), _rand((N, K), g, 0.1)
+    bias = torch.randn(N, generator=g)
+    res_wide = torch.randn(M, 2 * N + 8, generator=g).to(torch.bfloat16).cuda()
+    res = res_wide[:, 8:8 + N]                                        # row stride 2 N + 8 elements
+    o16 = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_BF16_BIAS_RES, a.cuda(), b.cuda(), o16, M=M, N=N, K=K, bias=bias.cuda(), res=res)
+    o32 = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_F32_BIAS_RES, a.cuda(), b.cuda(), o32, M=M, N=N, K=K, bias=bias.cuda(), res=res.float().contiguous())
+    want = o32.to(torch.bfloat16)
+    diff = (o16.float() - want.float()).abs()
+    # the two epilogues add bias and residual in a different order: a result on a rounding boundary may land one bf16 step apart
+    assert float((diff > 0).float().mean()) < 2e-3 and float((diff / want.float().abs().clamp_min(1.0)).max()) <= 2 ** -7
+    ref = (a.float() @ b.float().t() + bias + res.float().cpu())
+    torch.testing.assert_close(o16.float().cpu(), ref, atol=3e-2, rtol=1e-2)
+
+
 @pytest.mark.parametrize("M,N,K,splitk", [(128, 128, 64, 1), (192, 192, 197 * 2, 1), (768, 192, 1000, 4),
                                           (576, 192, 37, 1), (2304, 768, 197 * 8, 8), (512, 20032, 8, 1),
                                           (768, 768, 2048, 8), (2304, 768, 1024, 4), (768, 3072, 640, 1),

@@ -81,12 +81,15 @@ def test_forward_backward_vs_oracle(width, head_width, image, patch, loss_kind):
     assert not bad, bad
 
 
-def test_three_training_steps_vs_oracle():
+@pytest.mark.parametrize("stream,loss_tol,norm_tol", [("fp32", 4e-3, 0.03), ("bf16", 6e-3, 0.05)])
+def test_three_training_steps_vs_oracle(stream, loss_tol, norm_tol):
+    """``stream``: the forward residual stream in fp32 (default) or in bf16 (model.net.residual_stream=bf16, the reference's
+    own precision for it): on this width-64 toy the second carries ~1.5x the noise against the fp32 oracle, bounds stated."""
     data, losses, mc, module, net, optim = _pkg()
     import functools
     cfg, ocfg = tiny_cfgs(64, 32, 2, 32, 8)
     B = 16
-    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=5)
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=5, residual_stream=stream)
     perturb(n)
     params = {k: v.cpu() for k, v in n.state_dict().items()}
     loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
@@ -108,8 +111,9 @@ def test_three_training_steps_vs_oracle():
         loss.backward()
         nc = opt.step(grad_scale=1.0, max_norm=1.0)
         sched.step()
-        assert abs(float(loss.detach()) - float(ref["loss"])) < 4e-3, (step, float(loss.detach()), float(ref["loss"]))
-        assert abs(float(nc[0]) - float(ref["grad_norm"])) < 0.03 * float(ref["grad_norm"]) + 1e-4
+        assert abs(float(loss.detach()) - float(ref["loss"])) < loss_tol, (step, float(loss.detach()), float(ref["loss"]))
+        assert abs(float(nc[0]) - float(ref["grad_norm"])) < norm_tol * float(ref["grad_norm"]) + 1e-4
+    assert n.vision.stack.r16 == (stream == "bf16") and n.vision.stack.x_in[0].dtype == (torch.bfloat16 if stream == "bf16" else torch.float32)
     # after 3 AdamW steps the big weight matrices still track the oracle
     for k in ("visual.proj", "gene.fc2.weight", "visual.transformer.resblocks.1.mlp.c_fc.weight"):
         a, b = n.store.p(k).cpu(), tr.p[k].detach()
@@ -502,8 +506,8 @@ def test_gene_transformer_three_training_steps_vs_oracle():
         assert float((a - b).abs().max()) < 2.5e-3, k
 
 
-@pytest.mark.parametrize("overlap", ["1", "0"])
-def test_grad_checkpointing_is_bit_identical_and_saves_buffers(monkeypatch, overlap):
+@pytest.mark.parametrize("overlap,stream", [("1", "fp32"), ("0", "fp32"), ("1", "bf16")])
+def test_grad_checkpointing_is_bit_identical_and_saves_buffers(monkeypatch, overlap, stream):
     """set_grad_checkpointing (open_clip's CLIP API, src/open_clip/model.py:313-315) = activation recomputation: the
     LayerNorm outputs and the GELU output of a block are rebuilt in the backward from the saved residual stream /
     pre-activation with the forward's own kernels, so losses, gradients and two optimiser steps are bit-identical to the
@@ -516,7 +520,7 @@ def test_grad_checkpointing_is_bit_identical_and_saves_buffers(monkeypatch, over
     B = 24
     res = {}
     for ckpt in (False, True):
-        n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=5)
+        n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=5, residual_stream=stream)
         perturb(n)
         if ckpt:
             n.model.set_grad_checkpointing(True)

@@ -183,6 +183,51 @@ def test_layernorm_fwd_bwd(rows, d):
         assert torch.equal(dres2, dres) and torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(cs2, cs)
 
 
+@pytest.mark.parametrize("rows,d", [(50, 768), (197 * 2, 192), (33, 1024)])
+def test_layernorm_bf16_rows_and_bf16_gradient_stream(rows, d):
+    """sc_layernorm_fwd_x16 / _bwd_x16 / _bwd_g16: rows of the residual stream read as bf16 give the bits of the fp32 kernels
+    fed with float(x) (the widening is exact); the bf16 gradient stream gout = bf16(float(gin) + LNbwd(dy)) equals the fp32
+    buffer form started from float(gin); write_f32 = 0 leaves the fp32 buffer alone; the sparse form reads its class rows
+    from the fp32 buffer."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + 1)
+    dev = "cuda"
+    x16 = bf(torch.randn(rows, d, generator=g) * 2 + 0.5).cuda()
+    gamma, beta = torch.randn(d, generator=g).cuda(), torch.randn(d, generator=g).cuda()
+    dy = bf(torch.randn(rows, d, generator=g)).cuda()
+    gin = bf(torch.randn(rows, d, generator=g)).cuda()
+    y_a, y_b = (torch.empty(rows, d, dtype=torch.bfloat16, device=dev) for _ in range(2))
+    m_a, r_a, m_b, r_b = (torch.empty(rows, device=dev) for _ in range(4))
+    ops.layernorm_fwd(x16, gamma, beta, y_a, m_a, r_a, rows, d)
+    ops.layernorm_fwd(x16.float(), gamma, beta, y_b, m_b, r_b, rows, d)
+    assert torch.equal(y_a, y_b) and torch.equal(m_a, m_b) and torch.equal(r_a, r_b)
+
+    def bwd(x, **kw):
+        dres = kw.pop("dres0").clone()
+        dbf = torch.full((rows, d), 3.0, dtype=torch.bfloat16, device=dev)
+        dg, db, cs = (torch.empty(d, device=dev) for _ in range(3))
+        ops.layernorm_bwd(dy, x, m_a, r_a, gamma, dres, dbf, dg, db, cs, rows, d, **kw)
+        return dres, dbf, dg, db, cs
+    # fp32 buffer form on bf16 rows == on fp32 rows
+    a = bwd(x16, dres0=gin.float(), accumulate=True)
+    b = bwd(x16.float(), dres0=gin.float(), accumulate=True)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    # bf16 stream (fp32 rows and bf16 rows): same outgoing gradient and column sums; the fp32 buffer only on request
+    marker = torch.full((rows, d), 11.0, device=dev)
+    for xx in (x16.float(), x16):
+        c = bwd(xx, dres0=marker, accumulate=True, g16=True, g_in=gin, write_f32=False)
+        assert torch.equal(c[0], marker) and torch.equal(c[1], a[1]) and all(torch.equal(p, q) for p, q in zip(c[2:], a[2:]))
+        c = bwd(xx, dres0=marker, accumulate=True, g16=True, g_in=gin, write_f32=True)
+        assert torch.equal(c[0], a[0]) and torch.equal(c[1], a[1])
+    # sparse form: rows r % P == 0 take their incoming gradient from the fp32 buffer, the others start from zero
+    P = 5
+    sparse0 = torch.zeros(rows, d, device=dev)
+    sparse0[::P] = gin.float()[::P]
+    e = bwd(x16, dres0=sparse0, accumulate=-P, g16=True, write_f32=False)
+    f = bwd(x16.float(), dres0=sparse0, accumulate=True)
+    assert torch.equal(e[1], f[1]) and torch.equal(e[0], sparse0)
+
+
 def test_attention_cls_query_only():
     """q_rows = 1 (the last ViT block feeds only the CLS token on): outputs of the other rows are not written, their dq is
     written as exact zeros, dk / dv get the CLS query's contribution only, and dout of the unused rows does not matter."""
