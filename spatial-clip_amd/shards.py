@@ -257,6 +257,7 @@ class _PinnedRing:
 
 
 _END = object()
+_POOL_LOCK = threading.Lock()
 
 
 class ShardedSpatialDataModule:
@@ -369,7 +370,18 @@ class ShardedSpatialDataModule:
             sampler = self._eval_index_batches(len(index), self.batch_size, rank, W)
         rng = np.random.default_rng([self.seed, epoch, rank, 0 if train else 1])
         host_decode = os.environ.get("SC_PNG_HOST", "0") == "1"      # A/B: PIL on the host, as the reference's workers do
-        ring = self.__dict__.setdefault("_ring", _PinnedRing())
+        # staging buffers: one ring per producer that is alive (a validation loop inside an epoch runs while the training
+        # producer is parked on its full queue); rings are recycled, pinned memory is not allocated per epoch
+        pool = self.__dict__.setdefault("_ring_pool", [])
+        with _POOL_LOCK:
+            ring = pool.pop() if pool else _PinnedRing()
+        try:
+            yield from self._produce_groups(st, index, sampler, rng, train, dev, stream, ring, host_decode)
+        finally:
+            with _POOL_LOCK:
+                pool.append(ring)
+
+    def _produce_groups(self, st, index, sampler, rng, train, dev, stream, ring, host_decode) -> Iterator[Any]:
         ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         it = iter(sampler)
         while True:

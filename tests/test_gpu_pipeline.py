@@ -134,6 +134,13 @@ def test_shards_datamodule_feeds_the_trainer(tmp_path, monkeypatch):
     import time as _time
     _time.sleep(0.5)
     assert not [t for t in threading.enumerate() if t.name.startswith("sc-data-")]
+    # two loaders alive at once (a validation loop inside an epoch): each producer has its own staging buffers
+    it_train = iter(dm.train_dataloader())
+    first = next(it_train)
+    val = list(dm.val_dataloader())
+    rest = [first] + list(it_train)
+    assert len(val) == 3 and len(rest) == len(batches)
+    assert all(torch.equal(a["images"], b["images"]) for a, b in zip(rest, batches))
     from spatial_clip_amd import shards as _sh
     dense = np.stack([_sh.rank_weighted_vector(t, {g: i for i, g in enumerate(genes)}, len(genes)) for t in batches[0]["raw_text"]])
     assert np.array_equal(batches[0]["texts"].cpu().numpy(), dense)
