@@ -114,7 +114,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // stream and therefore its gradient are bf16 tensors): the incoming gradient is read from ``gin`` (bf16) instead of the fp32
 // ``dres``, and ``dres`` is written only when ``write_f32`` asks for it (the last hop in front of the stem) -- 10 instead of
 // 16 bytes per element cross HBM.  The sparse form (accumulate = -P) still reads its few class-token rows from ``dres``.
-template <int NV, bool Q8, bool XB = false>
+// GIN: the incoming gradient is the bf16 stream `gin` for every row (accumulate > 0): its loads are issued together with
+// dy / x instead of behind the two wave reductions (one exposed memory round trip per row less; gamma is re-read per row from
+// L1 so that the kernel stays at 128 VGPRs = 4 waves per SIMD).
+template <int NV, bool Q8, bool XB = false, bool GIN = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -127,12 +130,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
-    f32x4 ag[NV], ab[NV], ac[NV], gm[NV];
+    f32x4 ag[NV], ab[NV], ac[NV], gm[GIN ? 1 : NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         ag[i] = ab[i] = ac[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int e = i * 64 + lane;
-        gm[i] = e < nv ? ld4(gamma + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!GIN) gm[i] = e < nv ? ld4(gamma + e * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int row_ = blockIdx.x * 4 + wave; row_ < rows; row_ += gridDim.x * 4) {
         const int row = rows - 1 - row_;              // last row first: see ln_fwd_kernel
@@ -141,17 +144,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         const float* xr = x + (long long)row * ldx;
         const bf16* xrb = reinterpret_cast<const bf16*>(x) + (long long)row * ldx;
         f32x4 g[NV], xh[NV];
+        bf16x4 gin_raw[GIN ? NV : 1];
         float s1 = 0.f, s2 = 0.f;
+        if (GIN) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = i * 64 + lane;
+                if (e < nv) gin_raw[i] = *reinterpret_cast<const bf16x4*>(gin + (long long)row * ldgin + e * 4);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int e = i * 64 + lane;
             if (e < nv) {
                 const f32x4 dyv = ldbf4(dyr + e * 4);
                 const f32x4 xv = XB ? ldbf4(xrb + e * 4) : ld4(xr + e * 4);
+                const f32x4 gmv = GIN ? ld4(gamma + e * 4) : gm[GIN ? 0 : i];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     xh[i][c] = (xv[c] - mu) * rs;
-                    g[i][c] = dyv[c] * gm[i][c];
+                    g[i][c] = dyv[c] * gmv[c];
                     s1 += g[i][c];
                     s2 += g[i][c] * xh[i][c];
                     ag[i][c] += dyv[c] * xh[i][c];
@@ -172,7 +184,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             const int e = i * 64 + lane;
             if (e < nv) {
                 f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (acc_row) o = (gin != nullptr && accumulate > 0) ? ldbf4(gin + (long long)row * ldgin + e * 4) : ld4(dr + e * 4);
+                if (GIN) o = (f32x4){(float)gin_raw[i][0], (float)gin_raw[i][1], (float)gin_raw[i][2], (float)gin_raw[i][3]};
+                else if (acc_row) o = ld4(dr + e * 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     o[c] += rs * (g[i][c] - s1 - xh[i][c] * s2);
@@ -550,15 +563,19 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
     const size_t lds = (size_t)4 * 3 * d * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int nvv = (d / 4 + 63) / 64;
-#define SC_LN_BWD_Q(NV, Q, G)                                                                                           \
+#define SC_LN_BWD_QG(NV, Q, G, I)                                                                                       \
     do {                                                                                                                \
         if (lds > 48 * 1024)                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, Q, G>),                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, Q, G, I>),                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        ln_bwd_kernel<NV, Q, G><<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, \
-                                                        (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate,               \
-                                                        (unsigned char*)d8, ldd8, scale_inv, (const bf16*)gin, ldgin,   \
-                                                        write_f32);                                                     \
+        ln_bwd_kernel<NV, Q, G, I><<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres,      \
+                                                           lddres, (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate,    \
+                                                           (unsigned char*)d8, ldd8, scale_inv, (const bf16*)gin,       \
+                                                           ldgin, write_f32);                                           \
+    } while (0)
+#define SC_LN_BWD_Q(NV, Q, G)                                                                                           \
+    do {                                                                                                                \
+        if (gin != nullptr && accumulate > 0) SC_LN_BWD_QG(NV, Q, G, true); else SC_LN_BWD_QG(NV, Q, G, false);         \
     } while (0)
 #define SC_LN_BWD(NV)                                                                                                   \
     do {                                                                                                                \
@@ -569,6 +586,7 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
     else if (nvv == 4) SC_LN_BWD(4); else SC_LN_BWD(8);
 #undef SC_LN_BWD
 #undef SC_LN_BWD_Q
+#undef SC_LN_BWD_QG
     SC_LAUNCH_CHECK();
     if (dgamma == nullptr) return 0;      // deferred: the caller runs sc_layernorm_bwd_reduce (possibly on another stream)
     colvec_finalize_kernel<<<(3 * d + 63) / 64, 1024, 0, st>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
