@@ -554,3 +554,40 @@ def test_grad_checkpointing_is_bit_identical_and_saves_buffers(monkeypatch, over
     assert {"h.0", "a1.1", "a2.2"} <= res[False][3]
     assert not ({"h.0", "h.1", "h.2", "a1.0", "a2.1"} & res[True][3]) and {"h.rc0", "h.rc1", "a1.rc0", "a2.rc1"} <= res[True][3]
     assert "a1.3" in res[True][3]           # the CLS-only last block keeps its own LayerNorm output
+
+
+def test_residual_gradient_fp32_buffer_and_bf16_stream_agree(monkeypatch):
+    """SC_RES_GRAD=fp32 (the fp32 residual-gradient buffer of rounds 1-2) and the default bf16 stream on the same weights and
+    batch: same loss bits (the forward is untouched), gradients within 2 % relative L2 per tensor of each other (the stream rounds
+    the gradient to bf16 once per LayerNorm backward), both within the suite's 6 % of the fp32 oracle."""
+    data, losses, mc, module, net, optim = _pkg()
+    cfg, ocfg = tiny_cfgs(128, 64, 4, 48, 16)
+    B = 16
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=11)
+    perturb(n)
+    params = {k: v.cpu() for k, v in n.state_dict().items()}
+    batch = data.synthetic_batch(B, 48, cfg.gene.n_genes, K=4, step=0)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f = O.net_forward(batch["images"], batch["texts"], p, ocfg)
+    O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"]).backward()
+    m = module.SpatialClipLitModule(n, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True), None, None)
+    db = {k: v.cuda() for k, v in batch.items()}
+    res = {}
+    for mode in ("fp32", "bf16"):
+        monkeypatch.setenv("SC_RES_GRAD", mode)
+        n.store.grad.zero_()
+        out = m.model_step(db)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res[mode] = (float(out["loss"].detach()), {k: n.store.g(k).detach().cpu().double().clone() for k in params})
+    assert res["fp32"][0] == res["bf16"][0]
+    worst_pair, worst_ref = 0.0, 0.0
+    for k in params:
+        g_ref = p[k].grad.double() if p[k].grad is not None else None
+        a, b = res["fp32"][1][k], res["bf16"][1][k]
+        if float(a.norm()) > 1e-6:
+            worst_pair = max(worst_pair, float((a - b).norm() / a.norm()))
+        if g_ref is not None and float(g_ref.norm()) > 1e-5:
+            worst_ref = max(worst_ref, float((b - g_ref).norm() / g_ref.norm()))
+    print(f"fp32 buffer vs bf16 stream: worst relative L2 {worst_pair:.4f}; bf16 stream vs oracle {worst_ref:.4f}")
+    assert worst_pair < 0.02 and worst_ref < 0.06
