@@ -240,8 +240,8 @@ def main():
                     help="activation recomputation (LayerNorm outputs, GELU output): configs[4] at 1024 pairs per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: e4m3 forward GEMMs of the transformer blocks (BASELINE configs[4]); backward stays bf16")
-    ap.add_argument("--residual-stream", default="fp32", choices=["fp32", "bf16"],
-                    help="bf16: the forward residual stream kept in bf16 like the reference's autocast (default fp32)")
+    ap.add_argument("--residual-stream", default="bf16", choices=["fp32", "bf16"],
+                    help="the forward residual stream of the patch towers: bf16 like the reference's autocast (default) or fp32")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -37,10 +37,18 @@ int sc_abi_version(void);
  *   SC_EPI_F32           C(f32)  = acc ; with splitk > 1 partial slabs go to `slabs` and are reduced into C
  *   SC_EPI_BF16_BIAS_RES C(bf16) = acc + bias[N] + res[M,N](bf16)       (residual stream kept in bf16, as the reference's
  *                        autocast keeps it; `res` then points at bf16 data and ldres counts bf16 elements; one rounding)
+ *   SC_EPI_GELU_GRAD_PAIR  u = bf16(acc + bias) ; C(bf16) = gelu_erf'(u) ; C2(bf16) = gelu_erf(u)   (round 4: what the
+ *                        backward of nn.GELU needs is the factor gelu'(u), not u -- the forward already holds the erf
+ *                        pieces in registers, so the default path stores the factor and never u; the u-storing
+ *                        SC_EPI_GELU_PAIR / SC_EPI_BF16_DGELU pair stays for activation recomputation, which rebuilds
+ *                        h = gelu(u) from the saved u)
+ *   SC_EPI_BF16_MUL_AUX  C(bf16) = acc * aux[M,N](bf16)                 (c_proj dgrad x the stored gelu'(u): dU = dH . g;
+ *                        SC_EPI_BF16_DGELU rounds its recomputed factor to bf16 first, so both give the same bits)
  * N % 8 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.  Outer-dimension edges are handled. */
 enum { SC_GEMM_NT = 0, SC_GEMM_TN = 1 };
 enum { SC_EPI_BF16 = 0, SC_EPI_BF16_BIAS = 1, SC_EPI_F32_BIAS_RES = 2, SC_EPI_GELU_PAIR = 3,
-       SC_EPI_BF16_DGELU = 4, SC_EPI_F32 = 5, SC_EPI_BF16_BIAS_RES = 6 };
+       SC_EPI_BF16_DGELU = 4, SC_EPI_F32 = 5, SC_EPI_BF16_BIAS_RES = 6, SC_EPI_GELU_GRAD_PAIR = 7,
+       SC_EPI_BF16_MUL_AUX = 8 };
 int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                  void* C, int ldc, void* C2, int ldc2, const float* bias, const void* res, int ldres,
                  const void* aux, int ldaux, int splitk, float* slabs, void* stream);

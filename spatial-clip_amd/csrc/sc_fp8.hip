@@ -122,7 +122,7 @@ static int gemm_fp8_impl(int epi, const void* A8, int lda, const float* a_scale_
     SC_CHECK((lda % 16) == 0 && (ldb % 16) == 0 && ((uintptr_t)A8 % 16) == 0 && ((uintptr_t)B8 % 16) == 0,
              "sc_gemm_fp8: operand rows must be 16-byte aligned (lda=%d ldb=%d)", lda, ldb);
     const bool f32out = (epi == SC_EPI_F32 || epi == SC_EPI_F32_BIAS_RES);
-    SC_CHECK(epi != SC_EPI_BF16_DGELU || (aux != nullptr && (ldaux % 8) == 0), "sc_gemm_fp8: the GELU' epilogue needs aux (ldaux %% 8 == 0)");
+    SC_CHECK(!sc_epi_aux_mul(epi) || (aux != nullptr && (ldaux % 8) == 0), "sc_gemm_fp8: the GELU' epilogues need aux (ldaux %% 8 == 0)");
     SC_CHECK((N % (f32out ? 4 : 8)) == 0 && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0, "sc_gemm_fp8: N=%d ldc=%d", N, ldc);
     GemmArgs g;
     g.A = (const bf16*)A8; g.B = (const bf16*)B8; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
@@ -130,7 +130,7 @@ static int gemm_fp8_impl(int epi, const void* A8, int lda, const float* a_scale_
     g.aux = (const bf16*)aux; g.ldaux = ldaux; g.colsum = nullptr; g.tile_offset = 0;
     g.a_scale = a_scale_inv; g.b_scale = b_scale_inv; g.a_scale_scalar = a_scale_scalar;
     if (q8_out != nullptr) {
-        SC_CHECK(epi == SC_EPI_GELU_PAIR || epi == SC_EPI_BF16_DGELU, "sc_gemm_fp8_q: the e4m3 second output exists for the GELU pair / GELU' epilogues");
+        SC_CHECK(sc_epi_gelu_fwd(epi) || sc_epi_aux_mul(epi), "sc_gemm_fp8_q: the e4m3 second output exists for the GELU pair / GELU' epilogues");
         SC_CHECK(q8_scale != nullptr && q8_amax != nullptr && ldq8 >= N && (ldq8 % 8) == 0 && ((uintptr_t)q8_out % 8) == 0,
                  "sc_gemm_fp8_q: q8 output needs its scale, 64 amax slots and an 8-byte aligned row stride (ldq8=%lld)", ldq8);
         g.q8 = (unsigned char*)q8_out; g.ldq8 = ldq8; g.q8_scale = q8_scale; g.q8_amax = q8_amax;

@@ -222,6 +222,8 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     if (mode == SC_GEMM_NT) SC_CHECK((K % 8) == 0, "sc_gemm_bf16: NT needs K %% 8 == 0 (K=%d)", K);
     if (splitk < 1) splitk = 1;
     SC_CHECK(splitk == 1 || (epi == SC_EPI_F32 && slabs != nullptr), "sc_gemm_bf16: split-K needs EPI_F32 + slabs");
+    SC_CHECK(!sc_epi_aux_mul(epi) || (aux != nullptr && (ldaux % 8) == 0), "sc_gemm_bf16: epilogue %d needs aux (ldaux %% 8 == 0)", epi);
+    SC_CHECK(!sc_epi_gelu_fwd(epi) || (C2 != nullptr && (ldc2 % 8) == 0), "sc_gemm_bf16: epilogue %d needs the second output C2", epi);
     GemmArgs g;
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = (const float*)res; g.ldres = ldres;
@@ -270,6 +272,8 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     SC_CASE(SC_GEMM_NT, SC_EPI_GELU_PAIR)
     SC_CASE(SC_GEMM_NT, SC_EPI_BF16_DGELU)
     SC_CASE(SC_GEMM_NT, SC_EPI_BF16_BIAS_RES)
+    SC_CASE(SC_GEMM_NT, SC_EPI_GELU_GRAD_PAIR)
+    SC_CASE(SC_GEMM_NT, SC_EPI_BF16_MUL_AUX)
     SC_CASE(SC_GEMM_NT, SC_EPI_F32)
     SC_CASE(SC_GEMM_TN, SC_EPI_F32)
     SC_CASE(SC_GEMM_TN, SC_EPI_BF16)

@@ -301,6 +301,8 @@ int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs,
     SC_CASE(SC_GEMM_NT, SC_EPI_GELU_PAIR)
     SC_CASE(SC_GEMM_NT, SC_EPI_BF16_DGELU)
     SC_CASE(SC_GEMM_NT, SC_EPI_BF16_BIAS_RES)
+    SC_CASE(SC_GEMM_NT, SC_EPI_GELU_GRAD_PAIR)
+    SC_CASE(SC_GEMM_NT, SC_EPI_BF16_MUL_AUX)
     SC_CASE(SC_GEMM_NT, SC_EPI_F32)
     SC_CASE(SC_GEMM_TN, SC_EPI_F32)
 #undef SC_CASE

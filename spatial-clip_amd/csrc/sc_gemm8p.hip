@@ -43,13 +43,14 @@ SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
 // and an un-retired store holds back every later LDS-DMA of the same wave (vmcnt retires in order).  The accumulators
 // are packed to bf16 BEFORE the LDS trip (half the LDS bytes of the fp32 staging in sc_gemm_common.h), 16-B chunks
 // XOR-swizzled by row so the 8-B writes (2-way at worst) and 16-B reads spread over the banks.
-//   BF16 / BF16_BIAS: C = bf16(acc (+ bias));  GELU_PAIR: C = u = bf16(acc + bias), C2 = bf16(gelu(float(u))).
+//   BF16 / BF16_BIAS: C = bf16(acc (+ bias));  GELU_PAIR: C = u = bf16(acc + bias), C2 = bf16(gelu(float(u)));
+//   GELU_GRAD_PAIR: C = bf16(gelu'(float(u))), C2 as before, u itself is not stored.
 template <int EPI, bool Q8 = false>
 SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* strip, int row0, int col0, int lane) {
     float amax_lane = 0.f;
-    const float q8s = (Q8 && EPI == SC_EPI_GELU_PAIR && g.q8) ? *g.q8_scale : 0.f;
+    const float q8s = (Q8 && sc_epi_gelu_fwd(EPI) && g.q8) ? *g.q8_scale : 0.f;
     const int li = lane & 15, lg = lane >> 4;
-    constexpr bool kBias = (EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR);
+    constexpr bool kBias = (EPI == SC_EPI_BF16_BIAS || sc_epi_gelu_fwd(EPI));
     f32x4 bj[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -81,13 +82,25 @@ SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* st
             const u32x4 u = *reinterpret_cast<const u32x4*>(strip + r * 128 + ((rc ^ (r & 7)) << 4));
             const int grow = row0 + p * 32 + r;
             if (grow < g.M && gcol < g.N) {
-                *reinterpret_cast<u32x4*>(C + (size_t)grow * g.ldc + gcol) = u;
-                if (EPI == SC_EPI_GELU_PAIR) {
+                if (EPI != SC_EPI_GELU_GRAD_PAIR) *reinterpret_cast<u32x4*>(C + (size_t)grow * g.ldc + gcol) = u;
+                if (sc_epi_gelu_fwd(EPI)) {
                     union { u32x4 w; bf16x8 h; } x;
                     x.w = u;
                     bf16x8 o;
+                    if (EPI == SC_EPI_GELU_PAIR) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_gelu_fast((float)x.h[e]);
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_gelu_fast((float)x.h[e]);
+                    } else {                             // the backward's factor gelu'(u) instead of u
+                        bf16x8 gd;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float hv, gv;
+                            sc_gelu_both((float)x.h[e], hv, gv);
+                            o[e] = (bf16)hv;
+                            gd[e] = (bf16)gv;
+                        }
+                        *reinterpret_cast<bf16x8*>(C + (size_t)grow * g.ldc + gcol) = gd;
+                    }
                     *reinterpret_cast<bf16x8*>(C2 + (size_t)grow * g.ldc2 + gcol) = o;
                     if (Q8 && g.q8) {                    // e4m3 copy of h for the c_proj forward GEMM (GemmArgs::q8)
                         float r[8];
@@ -101,7 +114,7 @@ SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* st
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
-    if (Q8 && EPI == SC_EPI_GELU_PAIR && g.q8) sc_amax_publish(amax_lane, g.q8_amax);
+    if (Q8 && sc_epi_gelu_fwd(EPI) && g.q8) sc_amax_publish(amax_lane, g.q8_amax);
 }
 
 // ring slot of half-tile q (0: A half 0, 1: B half 0, 2: B half 1, 3: A half 1) of the K tile with parity D
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
 
     // Epilogue: bf16 outputs without an extra input tile go through the bf16 LDS strip (full-line stores, half the LDS
     // bytes); the fp32-residual, GELU' and fp32 epilogues keep the fp32 staging shared with sc_gemm256.hip.
-    if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) {
+    if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || sc_epi_gelu_fwd(EPI)) {
         epilogue_bf16_lds<EPI>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
     } else {
         const int mw = wr * 128;
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void gemm8pp_kernel(const GemmArgs g, int t
     const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 15, lg = lane >> 4;
     // stores one wave issues per interior tile (every lane in bounds): 4 passes x 4 full-line stores, two tensors -> 32
-    constexpr int ESTORES = (EPI == SC_EPI_GELU_PAIR) ? 32 : 16;
+    constexpr int ESTORES = sc_epi_gelu_fwd(EPI) ? 32 : 16;
 
     PStager S;
     S.nt = g.K / BK;
@@ -898,7 +911,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_f8_kernel(const GemmArgs g) {
             for (int j = 0; j < 4; ++j) acc[i][j] *= sb[j] * sa;
         }
     }
-    if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR) {
+    if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || sc_epi_gelu_fwd(EPI)) {
         epilogue_bf16_lds<EPI, true>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
     } else {
         const int mw = wr * 128;
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_f8_kernel(const GemmArgs g) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
         }
-        if (EPI == SC_EPI_BF16_DGELU && g.q8) sc_amax_publish(amax_lane, g.q8_amax);
+        if (sc_epi_aux_mul(EPI) && g.q8) sc_amax_publish(amax_lane, g.q8_amax);
     }
 }
 
@@ -954,6 +967,8 @@ int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st) {
     if (epi == SC_EPI_BF16_DGELU) return launch_f8<SC_EPI_BF16_DGELU>(g, nblocks, st);
     if (epi == SC_EPI_F32) return launch_f8<SC_EPI_F32>(g, nblocks, st);
     if (epi == SC_EPI_BF16_BIAS_RES) return launch_f8<SC_EPI_BF16_BIAS_RES>(g, nblocks, st);
+    if (epi == SC_EPI_GELU_GRAD_PAIR) return launch_f8<SC_EPI_GELU_GRAD_PAIR>(g, nblocks, st);
+    if (epi == SC_EPI_BF16_MUL_AUX) return launch_f8<SC_EPI_BF16_MUL_AUX>(g, nblocks, st);
     return 0;
 }
 
@@ -987,6 +1002,7 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
         if (epi == SC_EPI_BF16) return launch_persistent<SC_EPI_BF16>(g, nblocks, st);
         if (epi == SC_EPI_BF16_BIAS) return launch_persistent<SC_EPI_BF16_BIAS>(g, nblocks, st);
         if (epi == SC_EPI_GELU_PAIR) return launch_persistent<SC_EPI_GELU_PAIR>(g, nblocks, st);      // +1.5 % at 9.2 rounds
+        if (epi == SC_EPI_GELU_GRAD_PAIR) return launch_persistent<SC_EPI_GELU_GRAD_PAIR>(g, nblocks, st);
     }
     int rc = 0;
 #define SC_CASE(EPI) \
@@ -998,6 +1014,8 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     SC_CASE(SC_EPI_BF16_DGELU)
     SC_CASE(SC_EPI_F32)
     SC_CASE(SC_EPI_BF16_BIAS_RES)
+    SC_CASE(SC_EPI_GELU_GRAD_PAIR)
+    SC_CASE(SC_EPI_BF16_MUL_AUX)
 #undef SC_CASE
     return rc;
 }

@@ -49,9 +49,11 @@ constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: co
 // exact-erf GELU to 1.5e-7 (Abramowitz-Stegun 7.1.26) sharing one exp between erf and the Gaussian pdf, arranged for the
 // fewest VALU issue slots (the GELU epilogues are VALU-bound while the matrix pipe idles: profiles/r03_gelu_epilogue_decomposition.txt):
 //   y = |x| sqrt(log2(e) / 2);  e = 2^(-y^2) = exp(-x^2 / 2);  t = 1 / (1 + p' y);  q(t) = poly(t) / 2
-//   erf(|x| / sqrt 2) = 1 - 2 q e   =>   gelu(x) = x Phi(x) = max(x, 0) - |x| q e
-//                                        gelu'(x) = Phi(x) + x phi(x) = [x >= 0] + e (x / sqrt(2 pi) - copysign(q, x))
-// 11 (gelu) / 14 (gelu') plain VALU operations + v_rcp + v_exp per element; abs / neg ride on source modifiers.
+//   erf(|x| / sqrt 2) = 1 - 2 q e   =>   Phi(x) = 1/2 + copysign(1/2 - q e, x)          (the reference's 0.5 (1 + erf(x / sqrt 2)))
+//                                        gelu(x) = x Phi(x);   gelu'(x) = Phi(x) + x e / sqrt(2 pi)
+// 12 (gelu) / 13 (gelu') / 14 (both) plain VALU operations + v_rcp + v_exp per element; abs / neg ride on source modifiers.
+// Round 4: ONE definition of Phi for every path (GELU-pair epilogues, sc_gelu_bf16, the GELU' epilogue, and the forward
+// epilogue that stores gelu'(u) next to gelu(u)), so that the paths agree bit for bit by construction.
 SC_DEVICE void sc_gelu_qe(float x, float& q, float& e) {
     const float y = fabsf(x) * 0.84932180028801904f;                       // sqrt(log2(e) / 2)
     const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.2727374808792225f, y, 1.0f));   // 0.3275911 / sqrt(log2 e)
@@ -62,17 +64,33 @@ SC_DEVICE void sc_gelu_qe(float x, float& q, float& e) {
     r = __builtin_fmaf(r, t, 0.127414796f);
     q = r * t;
 }
-SC_DEVICE float sc_gelu_fast(float x) {
-    float q, e;
+SC_DEVICE float sc_gelu_phi(float x, float& e) {
+    float q;
     sc_gelu_qe(x, q, e);
-    return __builtin_fmaf(-fabsf(x), q * e, fmaxf(x, 0.0f));
+    return 0.5f + copysignf(__builtin_fmaf(-q, e, 0.5f), x);
+}
+SC_DEVICE float sc_gelu_fast(float x) {
+    float e;
+    return x * sc_gelu_phi(x, e);
 }
 SC_DEVICE float sc_gelu_grad_fast(float x) {
-    float q, e;
-    sc_gelu_qe(x, q, e);
-    const float step = x >= 0.0f ? 1.0f : 0.0f;
-    return __builtin_fmaf(e, __builtin_fmaf(x, 0.3989422804014327f, -copysignf(q, x)), step);
+    float e;
+    const float phi = sc_gelu_phi(x, e);
+    return __builtin_fmaf(x * e, 0.3989422804014327f, phi);
 }
+// h = gelu(x) and g = gelu'(x) from one evaluation of q, e (the forward epilogue SC_EPI_GELU_GRAD_PAIR)
+SC_DEVICE void sc_gelu_both(float x, float& h, float& g) {
+    float e;
+    const float phi = sc_gelu_phi(x, e);
+    h = x * phi;
+    g = __builtin_fmaf(x * e, 0.3989422804014327f, phi);
+}
+// the GELU' factor as every backward path applies it: rounded to bf16 first, because the default path reads it back
+// from the bf16 tensor the forward epilogue stored (SC_EPI_BF16_MUL_AUX) -- recomputation mode must give the same bits
+SC_DEVICE float sc_gelu_grad_bf16(float x) { return (float)(bf16)sc_gelu_grad_fast(x); }
+
+constexpr bool sc_epi_gelu_fwd(int e) { return e == SC_EPI_GELU_PAIR || e == SC_EPI_GELU_GRAD_PAIR; }   // two bf16 outputs
+constexpr bool sc_epi_aux_mul(int e) { return e == SC_EPI_BF16_DGELU || e == SC_EPI_BF16_MUL_AUX; }      // bf16 input tile, product
 
 // eight values -> eight e4m3 bytes (value * s, saturating at +-448)
 SC_DEVICE u32x2 sc_pack8_fp8(const float (&v)[8], float s) {
@@ -102,7 +120,7 @@ SC_DEVICE void sc_epi_put(float* ep, int row16, int col16, int li, int lg, f32x4
 template <int EPI>
 struct EpiRegs {
     static constexpr bool kRes = (EPI == SC_EPI_F32_BIAS_RES);
-    static constexpr bool kAux = (EPI == SC_EPI_BF16_DGELU || EPI == SC_EPI_BF16_BIAS_RES);    // a bf16 input tile
+    static constexpr bool kAux = (sc_epi_aux_mul(EPI) || EPI == SC_EPI_BF16_BIAS_RES);    // a bf16 input tile
     f32x4 r[kRes ? 16 : 1];
     bf16x8 a[kAux ? 8 : 1];
 };
@@ -120,7 +138,7 @@ SC_DEVICE void sc_epi_load(EpiRegs<EPI>& e, int gm0, int gn0, int lane, const Ge
             if (g.res && gm < mlim && gn < g.N) e.r[ps] = *reinterpret_cast<const f32x4*>(g.res + (size_t)gm * g.ldres + gn);
         }
     }
-    if (EPI == SC_EPI_BF16_DGELU) {
+    if (sc_epi_aux_mul(EPI)) {
         const int gn = gn0 + (lane & 7) * 8;
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
@@ -177,7 +195,7 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
         float bv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) bv[k] = 0.f;
-        if ((EPI == SC_EPI_BF16_BIAS || EPI == SC_EPI_GELU_PAIR || EPI == SC_EPI_BF16_BIAS_RES) && g.bias && gn < g.N) {
+        if ((EPI == SC_EPI_BF16_BIAS || sc_epi_gelu_fwd(EPI) || EPI == SC_EPI_BF16_BIAS_RES) && g.bias && gn < g.N) {
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + gn);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(g.bias + gn + 4);
 #pragma unroll
@@ -192,9 +210,10 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
             float v[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { v[k] = v0[k] + bv[k]; v[4 + k] = v1[k] + bv[4 + k]; }
-            if (EPI == SC_EPI_BF16_DGELU) {
+            if (sc_epi_aux_mul(EPI)) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= sc_gelu_grad_fast((float)e.a[ps][k]);
+                for (int k = 0; k < 8; ++k)          // aux = the pre-GELU tensor u (DGELU) or the stored factor gelu'(u) (MUL_AUX)
+                    v[k] *= (EPI == SC_EPI_BF16_DGELU) ? sc_gelu_grad_bf16((float)e.a[ps][k]) : (float)e.a[ps][k];
                 if (next_gm0 >= 0) {
                     const int gm2 = next_gm0 + row;
                     if (gm2 < g.M && gn < g.N)
@@ -217,8 +236,8 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
                 bf16x8 o;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = (bf16)v[k];
-                *reinterpret_cast<bf16x8*>(C + (size_t)gm * g.ldc + gn) = o;
-                if (Q8 && EPI == SC_EPI_BF16_DGELU && g.q8) {          // e4m3 copy of dU for the c_fc data-gradient GEMM
+                if (EPI != SC_EPI_GELU_GRAD_PAIR) *reinterpret_cast<bf16x8*>(C + (size_t)gm * g.ldc + gn) = o;
+                if (Q8 && sc_epi_aux_mul(EPI) && g.q8) {          // e4m3 copy of dU for the c_fc data-gradient GEMM
                     float r[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) { r[k] = (float)o[k]; *amax_lane = fmaxf(*amax_lane, fabsf(r[k])); }
@@ -228,6 +247,18 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
                     bf16x8 h;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) h[k] = (bf16)sc_gelu_fast((float)o[k]);
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.C2) + (size_t)gm * g.ldc2 + gn) = h;
+                }
+                if (EPI == SC_EPI_GELU_GRAD_PAIR) {          // C = gelu'(u), C2 = gelu(u), u = bf16(acc + bias) never stored
+                    bf16x8 h, gd;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float hv, gv;
+                        sc_gelu_both((float)o[k], hv, gv);
+                        h[k] = (bf16)hv;
+                        gd[k] = (bf16)gv;
+                    }
+                    *reinterpret_cast<bf16x8*>(C + (size_t)gm * g.ldc + gn) = gd;
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.C2) + (size_t)gm * g.ldc2 + gn) = h;
                 }
             }

@@ -134,7 +134,7 @@ class SpatialClipNet(torch.nn.Module):
                  cache_dir: Optional[str] = None, n_genes: Optional[int] = None, gene_hidden: Optional[int] = None,
                  device: Optional[str] = None, seed: int = 0, model_cfg: Optional[ModelCfg] = None,
                  tokenizer_vocab: Optional[str] = None, precision: str = "bf16", grad_checkpointing: bool = False,
-                 residual_stream: str = "fp32"):
+                 residual_stream: str = "bf16"):
         super().__init__()
         if aug_cfg is not None and not isinstance(aug_cfg, (dict, AugmentationCfg)) and not is_dataclass(aug_cfg) \
                 and not hasattr(aug_cfg, "items"):
@@ -172,9 +172,12 @@ class SpatialClipNet(torch.nn.Module):
             self._load_pretrained(pretrained)
         if grad_checkpointing:              # config key model.net.grad_checkpointing (open_clip: --grad-checkpointing)
             self.set_grad_checkpointing(True)
-        # config key model.net.residual_stream: "fp32" (default: the forward residual stream x + attn(..) + mlp(..) in fp32,
-        # better than the reference) or "bf16" (what the reference's bf16 autocast keeps: -1.7 % step time, 2.3x the feature
-        # noise against the fp32 oracle -- DESIGN.md section 7); the patch towers only
+        # config key model.net.residual_stream: "bf16" (default since round 4: what the reference's bf16 autocast keeps for
+        # the image tower -- conv1 emits bf16, class / positional embeddings are cast to it, LayerNorm casts back,
+        # src/open_clip/transformer.py:26-29,789-791) or "fp32" (the stream of rounds 1-3: +1.7 % step time, 0.4x the
+        # feature noise against the fp32 oracle -- DESIGN.md section 7).  Patch towers only: the reference's TEXT tower
+        # keeps an fp32 stream under autocast (fp32 embedding + fp32 LayerNorm output + bf16 branch = fp32), and so does
+        # this build's.
         if residual_stream not in ("fp32", "bf16"):
             raise ValueError(f"residual_stream {residual_stream!r}: 'fp32' or 'bf16'")
         self.residual_stream = residual_stream

@@ -11,7 +11,8 @@ from . import _lib
 from ._lib import check
 
 NT, TN = 0, 1
-EPI_BF16, EPI_BF16_BIAS, EPI_F32_BIAS_RES, EPI_GELU_PAIR, EPI_BF16_DGELU, EPI_F32, EPI_BF16_BIAS_RES = range(7)
+(EPI_BF16, EPI_BF16_BIAS, EPI_F32_BIAS_RES, EPI_GELU_PAIR, EPI_BF16_DGELU, EPI_F32, EPI_BF16_BIAS_RES, EPI_GELU_GRAD_PAIR,
+ EPI_BF16_MUL_AUX) = range(9)
 
 
 def _stream() -> int:

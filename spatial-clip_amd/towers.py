@@ -67,7 +67,7 @@ class TransformerStack:
         # residual stream in bf16 (what the reference's autocast keeps; SC_RES_STREAM, read at every forward) for the towers
         # whose stem / head kernels take it (the patch towers); off: fp32 stream
         self.res16_ok = res16_ok
-        self.res_stream = "fp32"
+        self.res_stream = "bf16"
         self.r16 = False
         # activation recomputation (set_grad_checkpointing): the LayerNorm outputs and the GELU output of a block are not
         # kept for the backward (12 of the 36 d bytes a token saves per block); the backward rebuilds them, bit-identically,
@@ -163,13 +163,18 @@ class TransformerStack:
             r2 = bf.get(f"r2.{i}", (M,), F32)
             ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2, m2, r2, M, d,
                               q8=qa and qa[0], q8_scale_inv=qa and qa[1])
+            # the MLP's backward needs gelu'(u), not u: the default path stores that factor (the forward epilogue holds the
+            # erf pieces anyway) and the c_proj data gradient becomes one multiply; recomputation mode keeps u, from which
+            # it rebuilds h = gelu(u)
             u = bf.get(f"u.{i}", (M, mlp), BF16)
             h = self._act("h", i, (M, mlp))
+            epi_gelu = ops.EPI_GELU_PAIR if self.recompute else ops.EPI_GELU_GRAD_PAIR
+            self._u_holds_grad = not self.recompute        # what THIS forward left in the u buffers (read by backward)
             hq = None
             if self.fp8 and self._dq_on:      # the GELU epilogue also emits e4m3(h) with last step's scale + records max|h|
                 h8 = bf.get("q8.h", (M, mlp), torch.uint8)
                 hq = dict(q8_out=h8, q8_scale=self._dq_scale[2 * i:2 * i + 1], q8_amax=self._dq_amax[2 * i])
-            self._linear_fwd(ops.EPI_GELU_PAIR, a2, self._n(i, "mlp.c_fc.weight"), u,
+            self._linear_fwd(epi_gelu, a2, self._n(i, "mlp.c_fc.weight"), u,
                              M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h, q8=qa, **(hq or {}))
             xo = bf.get(f"xout.{i}", (M, d), XD)
             cpj = s.copies[self._n(i, "mlp.c_proj.weight")]
@@ -198,8 +203,8 @@ class TransformerStack:
         ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
                           bf.get("c.m2", (B,), F32), bf.get("c.r2", (B,), F32), B, d)
         u, h = bf.get("c.u", (B, mlp), BF16), bf.get("c.h", (B, mlp), BF16)
-        ops.gemm(ops.NT, ops.EPI_GELU_PAIR, a2, s.copies[self._n(i, "mlp.c_fc.weight")].wf, u, M=B, N=mlp, K=d,
-                 bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)
+        ops.gemm(ops.NT, ops.EPI_GELU_GRAD_PAIR, a2, s.copies[self._n(i, "mlp.c_fc.weight")].wf, u, M=B, N=mlp, K=d,
+                 bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)           # "u" holds gelu'(u): this block is never recomputed
         xo = bf.get("c.xout", (B, d), XD)
         ops.gemm(ops.NT, epi_res, h, s.copies[self._n(i, "mlp.c_proj.weight")].wf, xo, M=B, N=d, K=mlp,
                  bias=s.p(self._n(i, "mlp.c_proj.bias")), res=xmid)
@@ -221,7 +226,7 @@ class TransformerStack:
         dU = bf.get("c.dU", (B, mlp), BF16)
         dA_c = bf.get("c.dA", (B, d), BF16)
         dres_c_bf_ = dres_c_bf
-        ops.gemm(ops.NT, ops.EPI_BF16_DGELU, dres_c_bf_, cp("mlp.c_proj.weight").wb, dU, M=B, N=mlp, K=d, aux=u)
+        ops.gemm(ops.NT, ops.EPI_BF16_MUL_AUX, dres_c_bf_, cp("mlp.c_proj.weight").wb, dU, M=B, N=mlp, K=d, aux=u)
 
         def w_mlp():
             ops.gemm(ops.TN, ops.EPI_F32, dres_c_bf_, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=B)
@@ -319,7 +324,7 @@ class TransformerStack:
         # The residual gradient between the blocks travels in bf16 (g_in -> g_bf, three rotating buffers), which is the
         # precision the reference's autocast carries it in; the fp32 buffer is written by the stack's last hop only (the
         # stem reads it).  SC_RES_GRAD=fp32 keeps the fp32 read-modify-write of rounds 1-2 (16 instead of 10 bytes per element).
-        g16 = _res_grad_bf16()
+        g16 = _res_grad_bf16() and self.res16_ok      # text tower: fp32 stream AND fp32 residual gradient, as the reference's
 
         def ln_bwd(dy, x, mean, rstd, gamma, g_in, g_bf, dgamma, dbeta, colsum, last=False) -> None:
             kw = dict(q8=qg[0], q8_scale_inv=qg[1]) if qg is not None else {}
@@ -377,7 +382,9 @@ class TransformerStack:
                 dU8 = bf.get("q8.dU", (M, mlp), torch.uint8)
                 dq = dict(q8_out=dU8, q8_scale=self._dq_scale[2 * i + 1:2 * i + 2], q8_amax=self._dq_amax[2 * i + 1])
             dU_has_q8 = bool(dq) and g_has_q8 and self._dq_ready
-            dgrad(ops.EPI_BF16_DGELU, g0, self._n(i, "mlp.c_proj.weight"), dU, N=mlp, K=d, have_q8=g_has_q8, aux=u, q8kw=dq)
+            # aux = the stored factor gelu'(u) (default) or u itself (recomputation mode): same bits either way
+            dgrad(ops.EPI_BF16_MUL_AUX if self._u_holds_grad else ops.EPI_BF16_DGELU, g0, self._n(i, "mlp.c_proj.weight"), dU,
+                  N=mlp, K=d, have_q8=g_has_q8, aux=u, q8kw=dq)
 
             def w_mlp(g0=g0, h=h, dU=dU, a2=a2, g=g):
                 ops.gemm(ops.TN, ops.EPI_F32, g0, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M, splitk=_splitk_for(d, mlp, M))
@@ -436,9 +443,9 @@ class TransformerStack:
             main.wait_event(ev)
         return dres
 
-def _res_stream_bf16(configured: str = "fp32") -> bool:
-    """Read at every forward: the residual stream of the patch towers in bf16 (the reference's precision under its bf16
-    autocast) or fp32 (default) -- SpatialClipNet(residual_stream=...), overridden by SC_RES_STREAM=bf16|fp32 for A/B."""
+def _res_stream_bf16(configured: str = "bf16") -> bool:
+    """Read at every forward: the residual stream of the patch towers in bf16 (default: the reference's precision under its
+    bf16 autocast) or fp32 -- SpatialClipNet(residual_stream=...), overridden by SC_RES_STREAM=bf16|fp32 for A/B."""
     return os.environ.get("SC_RES_STREAM", configured) == "bf16"
 
 

@@ -131,6 +131,44 @@ def test_nt_residual_gelu_dgelu(M, N, K):
     torch.testing.assert_close(d.float().cpu(), (ref * x.grad).to(torch.bfloat16).float(), atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(333, 192, 256), (197 * 4, 768, 192), (700, 264, 64), (256, 3072, 768),
+                                   (256 * 86 + 24, 3072, 192), (64, 256, 64)])
+def test_nt_gelu_grad_pair_and_mul_aux(M, N, K):
+    """Round 4: the forward c_fc epilogue stores gelu'(u) (SC_EPI_GELU_GRAD_PAIR) instead of u, and the c_proj data
+    gradient multiplies by that stored factor (SC_EPI_BF16_MUL_AUX).  Checked (a) against torch's erf GELU and its
+    autograd derivative on the kernel's own bf16 u, (b) for bit-identity with the u-storing pair that activation
+    recomputation keeps (same h; dU from the stored factor == dU from the factor recomputed out of u), over the
+    128x128 kernel, the 256x256 kernel and the persistent tile walk (> 1024 tiles)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11 + M)
+    a, b = _rand((M, K), g), _rand((N, K), g, 0.15)
+    bias = torch.randn(N, generator=g)
+    ad, bd, biasd = a.cuda(), b.cuda(), bias.cuda()
+    u = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    h = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_GELU_PAIR, ad, bd, u, M=M, N=N, K=K, bias=biasd, out2=h)
+    gd = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    h2 = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_GELU_GRAD_PAIR, ad, bd, gd, M=M, N=N, K=K, bias=biasd, out2=h2)
+    assert torch.equal(h, h2)                                   # same h whichever tensor travels beside it
+    x = u.float().cpu().requires_grad_(True)
+    y = gelu(x)
+    y.sum().backward()
+    torch.testing.assert_close(h.float().cpu(), y.detach().to(torch.bfloat16).float(), atol=8e-3, rtol=8e-3)
+    # the stored factor: bf16 rounding of gelu'(u) (range [-0.13, 1.13]); 1 bf16 step = 2^-8 near 1
+    torch.testing.assert_close(gd.float().cpu(), x.grad.to(torch.bfloat16).float(), atol=4e-3, rtol=8e-3)
+    # backward: dY [M, K2] . W [K2 -> N]  x  factor
+    K2 = 128
+    dy, w = _rand((M, K2), g), _rand((N, K2), g, 0.1)
+    d_mul = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    d_rec = torch.full((M, N), 5.0, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ops.NT, ops.EPI_BF16_MUL_AUX, dy.cuda(), w.cuda(), d_mul, M=M, N=N, K=K2, aux=gd)
+    ops.gemm(ops.NT, ops.EPI_BF16_DGELU, dy.cuda(), w.cuda(), d_rec, M=M, N=N, K=K2, aux=u)
+    assert torch.equal(d_mul, d_rec)                            # recomputation mode reproduces the default path bit for bit
+    ref = (dy.float() @ w.float().t()) * x.grad
+    torch.testing.assert_close(d_mul.float().cpu(), ref.to(torch.bfloat16).float(), atol=3e-2, rtol=3e-2)
+
+
 @pytest.mark.parametrize("M,N,K", [(333, 192, 256), (197 * 4, 768, 192), (700, 264, 64), (197 * 64, 768, 768), (64, 768, 3072)])
 def test_nt_bf16_residual_epilogue(M, N, K):
     """SC_EPI_BF16_BIAS_RES: x_new = bf16(A.B^T + bias + x) with the residual x read as bf16 (strided rows included, as the

@@ -42,11 +42,16 @@ def perturb(netobj, seed=11):
 
 @pytest.mark.parametrize("width,head_width,image,patch", [(64, 32, 32, 8), (128, 64, 48, 16)])
 @pytest.mark.parametrize("loss_kind", ["clip", "spatial"])
-def test_forward_backward_vs_oracle(width, head_width, image, patch, loss_kind):
+@pytest.mark.parametrize("stream,loss_tol", [("bf16", 6e-3), ("fp32", 4e-3)])
+def test_forward_backward_vs_oracle(width, head_width, image, patch, loss_kind, stream, loss_tol):
+    """``stream``: the image tower's residual stream -- bf16 (the default since round 4: the reference's autocast precision)
+    or fp32.  Loss bound of this 12-pair toy: the reference's own policy (torch.autocast bf16 on the oracle) moves its loss
+    by up to 5.2e-3 (profiles/r04_autocast_gradient_noise_tiny_model.txt); the 1e-3 of the north-star is asserted at the
+    headline size (tests/test_gpu_fullsize.py)."""
     data, losses, mc, module, net, optim = _pkg()
     cfg, ocfg = tiny_cfgs(width, head_width, 2, image, patch)
     B = 12
-    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=3)
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=3, residual_stream=stream)
     perturb(n)
     params = {k: v.cpu() for k, v in n.state_dict().items()}
     batch = data.synthetic_batch(B, image, cfg.gene.n_genes, K=4, step=0)
@@ -68,14 +73,17 @@ def test_forward_backward_vs_oracle(width, head_width, image, patch, loss_kind):
     out = m.model_step(db)
     assert (out["image_features"].cpu() - f["image_features"].detach()).abs().max() < 5e-3
     assert (out["text_features"].cpu() - f["text_features"].detach()).abs().max() < 5e-3
-    assert abs(float(out["loss"].detach()) - float(lo.detach())) < 4e-3   # tiny batch: bf16 feature noise is not averaged out
+    assert abs(float(out["loss"].detach()) - float(lo.detach())) < loss_tol   # tiny batch: bf16 feature noise is not averaged out
     out["loss"].backward()
     torch.cuda.synchronize()
     bad = []
     for k in params:
         g_ref = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
         g = n.store.g(k).cpu()
-        tol = 0.03 * float(g_ref.abs().max()) + 1e-6
+        # 4 % of the tensor's max-abs.  The reference's OWN precision policy (torch.autocast bf16 on the fp32 oracle, same
+        # toy geometry, 8 seeds: tools/autocast_noise.py, profiles/r04_autocast_gradient_noise_tiny_model.txt) puts the
+        # worst tensor at 1.8-3.1 % on this metric; this build measures <= 3.1 %.
+        tol = 0.04 * float(g_ref.abs().max()) + 1e-6
         if float((g - g_ref).abs().max()) > tol:
             bad.append((k, float((g - g_ref).abs().max()), float(g_ref.abs().max())))
     assert not bad, bad
@@ -431,12 +439,17 @@ def genetr_cfgs(width=64, head_width=32, layers=2, image=32, patch=8, embed=32, 
 
 
 @pytest.mark.parametrize("gwidth,ghead,n_genes", [(64, 32, 300), (128, 64, 1000)])
-def test_gene_transformer_forward_backward_vs_oracle(gwidth, ghead, n_genes):
+@pytest.mark.parametrize("stream,g_tol,l2_tol", [("bf16", 0.08, 0.07), ("fp32", 0.05, 0.04)])
+def test_gene_transformer_forward_backward_vs_oracle(gwidth, ghead, n_genes, stream, g_tol, l2_tol):
+    """``stream``: residual stream of the two patch towers (bf16 = default).  Gradient bounds of this 12-pair toy with two
+    multi-layer bf16 towers: the reference's own precision policy (torch.autocast bf16 on the oracle, same geometry) sits at
+    0.8-3.4x the fp32-stream bound on this criterion (profiles/r04_autocast_gradient_noise_tiny_model.txt); this build
+    measures 1.4x with bf16 streams, < 1x with fp32 streams."""
     data, losses, mc, module, net, optim = _pkg()
     cfg, ocfg = genetr_cfgs(n_genes=n_genes, gwidth=gwidth, ghead=ghead, glayers=3)
     assert cfg.gene.tokens == (n_genes + 63) // 64 + 1
     B = 12
-    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=4)
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=4, residual_stream=stream)
     perturb(n)
     params = {k: v.cpu() for k, v in n.state_dict().items()}
     assert set(params) == set(O.init_params(ocfg, 0)), "oracle / product parameter names disagree"
@@ -461,11 +474,11 @@ def test_gene_transformer_forward_backward_vs_oracle(gwidth, ghead, n_genes):
         g = n.store.g(k).cpu()
         # 5 % of the tensor's max-abs: both towers are now multi-layer bf16 transformers, and the feature noise of each
         # (<= 5e-3) enters the other tower's gradient through the similarity matrix
-        tol = 0.05 * float(g_ref.abs().max()) + 1e-6
+        tol = g_tol * float(g_ref.abs().max()) + 1e-6
         # a tensor also passes on its relative L2 error: the max over the few dozen elements of a small LayerNorm gain
         # gradient (|g| ~ 1e-3) sits at the edge of the element-wise bound from one build to the next
         l2 = float((g - g_ref).norm() / (g_ref.norm() + 1e-12))
-        if float((g - g_ref).abs().max()) > tol and l2 > 0.04:
+        if float((g - g_ref).abs().max()) > tol and l2 > l2_tol:
             bad.append((k, float((g - g_ref).abs().max()), float(g_ref.abs().max()), l2))
     assert not bad, bad
     raw = n.model.encode_text(batch["texts"].cuda(), normalize=False).cpu()          # pre-normalisation features
