@@ -256,6 +256,9 @@ int sc_pcc_rows(const float* pred, long long ldp, const float* target, long long
 /* logit_scale.exp() (src/models/components/spatial_clip_net.py:51) and its backward dx = dy * y * mult. */
 int sc_exp_scalar(const float* x, float* y, void* stream);
 int sc_exp_scalar_bwd(const float* y, const float* dy, float* dx, float mult, void* stream);
+/* out[n] = x[n] * *s (device scalar): the upstream gradient of the loss applied to the gradients the fused head formed for
+ * an upstream gradient of 1 (the `grad_output` of autograd for the loss node, src/models/spatial_clip_module.py:103-108). */
+int sc_scale_by_scalar(const float* x, const float* s, float* out, long long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ input pipeline
  *  the data-dependent dataloader steps, on the device.

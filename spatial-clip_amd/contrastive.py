@@ -32,7 +32,8 @@ def contrastive_forward_backward(
         cap_logit_scale: Optional[float] = None, temp_reg_weight: float = 0.0, neighbor_alpha_scale: float = 1.0,
         logit_bias: Optional[torch.Tensor] = None, recall_hits: Optional[torch.Tensor] = None,
         recall_rows: Optional[tuple] = None,
-        late_all_image: Optional[Callable[[], torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        late_all_image: Optional[Callable[[], torch.Tensor]] = None, join_local: bool = False,
+        want_recall: bool = True) -> Dict[str, torch.Tensor]:
     """Returns loss (0-d), d_image/d_text [B,D] (direct terms), d_all [G,2D] = d_all_image | d_all_text (this rank's
     contribution to EVERY rank's features = the operand of the reduce-scatter that is the autograd of
     torch.distributed.nn.all_gather, loss.py:50-52), d_scale, d_bias, recall_hits (R@1/5/10 hit counters).
@@ -40,7 +41,10 @@ def contrastive_forward_backward(
     ``late_all_image``: callable returning ``all_image`` -- invoked only after the first similarity GEMM
     (image . all_text^T, which does not need it) has been enqueued, so a still-running all-gather of the image
     features overlaps with that GEMM.  ``recall_rows = (row0, n)``: the rows of z[0] whose diagonal block feeds R@k
-    (default: all B rows, diagonal at column rank*B)."""
+    (default: all B rows, diagonal at column rank*B).  ``join_local`` (single process, G == B): the gathered-feature
+    terms are accumulated straight onto the direct terms by the GEMMs (``d_image`` / ``d_text`` then hold the complete
+    feature gradients and no ``d_all`` is formed).  ``want_recall=False`` skips the R@k counters.
+    ``grads``: one flat fp32 buffer [2 B D + 1] = d_image | d_text | d_scale (one launch scales all three in backward)."""
     f_i = _rows(image_features)
     f_t = _rows(text_features)
     a_t = f_t if all_text is None else _rows(all_text)
@@ -90,27 +94,36 @@ def contrastive_forward_backward(
     rowstats = torch.empty((2 * B, 4), dtype=torch.float32, device=dev)
     loss_out = torch.empty(4, dtype=torch.float32, device=dev)
     ops.contrastive_loss_fwd(z, B, G, scale, cap, bias, lab_col, lab_w, nlab, w, rowstats, loss_out)
-    if recall_hits is None:
-        recall_hits = torch.zeros(3, dtype=torch.int32, device=dev)
-    if recall_rows is None:
-        ops.recall_hits(z[0], G, B, rank * B, recall_hits)
-    else:           # a window of a [G,G] matrix: rows row0.. whose diagonal sits at the same column offset
-        row0, nrow = recall_rows
-        ops.recall_hits(z[0][row0:], G, nrow, row0, recall_hits)
+    if want_recall or recall_hits is not None:
+        if recall_hits is None:
+            recall_hits = torch.zeros(3, dtype=torch.int32, device=dev)
+        if recall_rows is None:
+            ops.recall_hits(z[0], G, B, rank * B, recall_hits)
+        else:           # a window of a [G,G] matrix: rows row0.. whose diagonal sits at the same column offset
+            row0, nrow = recall_rows
+            ops.recall_hits(z[0][row0:], G, nrow, row0, recall_hits)
     rowgrad = torch.empty((2 * B, 2), dtype=torch.float32, device=dev)
-    d_scale = torch.empty(1, dtype=torch.float32, device=dev)
+    grads = torch.empty(2 * B * D + 1, dtype=torch.float32, device=dev)     # d_image | d_text | d_scale
+    d_image, d_text = grads[:B * D].view(B, D), grads[B * D:2 * B * D].view(B, D)
+    d_scale = grads[2 * B * D:]
     d_bias = torch.empty(1, dtype=torch.float32, device=dev)
     ops.contrastive_loss_bwd(z, B, G, scale, cap, bias, lab_col, lab_w, nlab, w, rowstats, loss_out, None, rowgrad,
                              d_scale, d_bias)
-    d_image = torch.empty((B, D), dtype=torch.float32, device=dev)
-    d_text = torch.empty((B, D), dtype=torch.float32, device=dev)
+    direct = [(z[0], G, 1, a_t, 1, a_t.stride(0), d_image, D, B, D, G),     # dz_it . all_text        (K = G: first)
+              (z[1], G, 1, a_i, 1, a_i.stride(0), d_text, D, B, D, G)]      # dz_ti . all_image
+    out = {"loss": loss_out[0], "gap": loss_out[1], "d_image": d_image, "d_text": d_text, "d_scale": d_scale[0],
+           "d_bias": d_bias[0], "recall_hits": recall_hits, "grads": grads}
+    if join_local:
+        if G != B or rank != 0:
+            raise ValueError("join_local: only for the single-process head (G == B)")
+        ops.sgemm_grouped(direct)
+        ops.sgemm_grouped([(z[0], 1, G, f_i, 1, f_i.stride(0), d_text, D, G, D, B, 1),     # += dz_it^T . image = d all_text
+                           (z[1], 1, G, f_t, 1, f_t.stride(0), d_image, D, G, D, B, 1)])   # += dz_ti^T . text  = d all_image
+        return out
     d_all = torch.empty((G, 2 * D), dtype=torch.float32, device=dev)       # d_all_image | d_all_text
-    ops.sgemm_grouped([
-        (z[0], G, 1, a_t, 1, a_t.stride(0), d_image, D, B, D, G),            # dz_it . all_text        (K = G: first)
-        (z[1], G, 1, a_i, 1, a_i.stride(0), d_text, D, B, D, G),             # dz_ti . all_image
+    ops.sgemm_grouped(direct + [
         (z[0], 1, G, f_i, 1, f_i.stride(0), d_all[:, D:], 2 * D, G, D, B),   # dz_it^T . image  -> d all_text
         (z[1], 1, G, f_t, 1, f_t.stride(0), d_all[:, :D], 2 * D, G, D, B),   # dz_ti^T . text   -> d all_image
     ])
-    return {"loss": loss_out[0], "gap": loss_out[1], "d_image": d_image, "d_text": d_text, "d_all": d_all,
-            "d_all_image": d_all[:, :D], "d_all_text": d_all[:, D:], "d_scale": d_scale[0], "d_bias": d_bias[0],
-            "recall_hits": recall_hits}
+    out.update(d_all=d_all, d_all_image=d_all[:, :D], d_all_text=d_all[:, D:])
+    return out

@@ -529,6 +529,11 @@ extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, c
     }
     // 1) single-pass (non-causal, L <= 224): 232-256 us per ViT-B/16 layer; 2) persistent two-pass with loader waves
     // (also causal): 254 us; 3) one workgroup per head: 268-296 us.  The switches are read per call (tests select a path).
+    const bool ring_on = !(getenv("SC_ATTN_BWD3") && getenv("SC_ATTN_BWD3")[0] == '0');
+    if (ring_on && sc_attn_bwd_ring(qkv, out, dout, lse, delta, dqkv, B, L, Lq, H, dh, causal, st)) {   // round 4: dS ring + MFMA-chain dQ
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     const bool single_on = !(getenv("SC_ATTN_BWD1") && getenv("SC_ATTN_BWD1")[0] == '0');
     if (single_on && sc_attn_bwd_single_pass(qkv, out, dout, lse, delta, dqkv, B, L, Lq, H, dh, causal, st)) {
         SC_LAUNCH_CHECK();

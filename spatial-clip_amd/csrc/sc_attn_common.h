@@ -14,6 +14,10 @@ int sc_attn_fwd_persistent(const void* qkv, void* out, float* lse, int B, int L,
 int sc_attn_bwd_single_pass(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                             int B, int L, int Lq, int H, int dh, int causal, hipStream_t st);
 
+// sc_attention_bwd3.hip (round 4): single pass, dQ by MFMA chains over a ring of dS tiles, rolling Q / dO refill; 1 = launched
+int sc_attn_bwd_ring(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+                     int L, int Lq, int H, int dh, int causal, hipStream_t st);
+
 // sc_attention_bwd2.hip: persistent two-pass backward with loader waves; 1 = launched, 0 = shape out of range
 int sc_attn_bwd_persistent(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            int B, int L, int Lq, int H, int dh, int causal, hipStream_t st);

@@ -352,6 +352,24 @@ extern "C" int sc_recall_hits(const float* z_image_rows, int G, int B, int col0,
     return 0;
 }
 
+// out[i] = x[i] * *s : the upstream gradient of the loss (a device scalar) applied to the feature / scale gradients the
+// fused head produced for an upstream gradient of 1 (autograd's loss.backward() passes 1.0, but any scalar is honoured)
+__global__ void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ out,
+                                       long long n) {
+    const float f = *s;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = x[i] * f;
+}
+
+extern "C" int sc_scale_by_scalar(const float* x, const float* s, float* out, long long n, void* stream) {
+    SC_CHECK(n > 0 && x != nullptr && s != nullptr && out != nullptr, "sc_scale_by_scalar: bad arguments (n=%lld)", n);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    scale_by_scalar_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, s, out, n);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sc_exp_scalar(const float* x, float* y, void* stream) {
     exp_scalar_kernel<<<1, 1, 0, (hipStream_t)stream>>>(x, y);
     SC_LAUNCH_CHECK();

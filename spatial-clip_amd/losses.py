@@ -11,7 +11,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import comm
+from . import comm, ops
 from .contrastive import contrastive_forward_backward
 
 
@@ -43,7 +43,7 @@ class _ContrastiveFn(torch.autograd.Function):
                       all_text_tile_ids=all_ids_t, neighbor_tile_ids=kw.get("neighbor_tile_ids"),
                       neighbor_alphas=kw.get("neighbor_alphas"), cap_logit_scale=owner.cap_logit_scale,
                       temp_reg_weight=owner.temp_reg_weight, neighbor_alpha_scale=owner.neighbor_alpha_scale,
-                      logit_bias=kw.get("logit_bias"), recall_hits=owner.recall_hits)
+                      logit_bias=kw.get("logit_bias"), recall_hits=owner.recall_hits, want_recall=False)
         if dist_on and owner.mode == "clip" and not owner.local_loss:
             # loss.py:119-121: every rank forms the full [G,G] logits of the global batch (labels arange(G))
             if late is not None:
@@ -58,7 +58,8 @@ class _ContrastiveFn(torch.autograd.Function):
             d_img, d_txt = both[:, :D].contiguous(), both[:, D:].contiguous()
         else:
             res = contrastive_forward_backward(img, txt, logit_scale.detach(), all_image=all_i, all_text=all_t,
-                                               rank=rank if dist_on else 0, late_all_image=late, **common)
+                                               rank=rank if dist_on else 0, late_all_image=late, join_local=not dist_on,
+                                               **common)
             if dist_on and owner.gather_with_grad:
                 # autograd of torch.distributed.nn.all_gather (loss.py:50-52): SUM over ranks, keep own rows
                 both = comm.reduce_scatter_sum(res["d_all"])
@@ -66,16 +67,21 @@ class _ContrastiveFn(torch.autograd.Function):
                 d_txt = res["d_text"] + both[:, D:]
             elif dist_on:
                 d_img, d_txt = res["d_image"], res["d_text"]     # loss.py:54-63 with local_loss: remote shards detached
-            else:
-                d_img = res["d_image"] + res["d_all_image"]
-                d_txt = res["d_text"] + res["d_all_text"]
+            else:           # single process: the head's GEMMs accumulated the gathered-feature terms onto the direct ones
+                d_img, d_txt = res["d_image"], res["d_text"]
+        ctx.flat = res["grads"] if d_img is res["d_image"] and d_txt is res["d_text"] else None
         ctx.save_for_backward(d_img, d_txt, res["d_scale"])
         owner.last = res
-        return res["loss"].clone()
+        return res["loss"]
 
     @staticmethod
     def backward(ctx, g):
         d_img, d_txt, d_s = ctx.saved_tensors
+        g = g.detach().reshape(1).float()
+        if ctx.flat is not None and g.is_cuda:     # d_image | d_text | d_scale are one buffer: one launch applies the upstream gradient
+            out = ops.scale_by_scalar(ctx.flat, g, torch.empty_like(ctx.flat))
+            n = d_img.numel()
+            return out[:n].view_as(d_img), out[n:2 * n].view_as(d_txt), out[2 * n], None, None
         return d_img * g, d_txt * g, d_s * g, None, None
 
 

@@ -398,6 +398,15 @@ def exp_scalar(x, y):
     return y
 
 
+def scale_by_scalar(x: torch.Tensor, s: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out = x * s (s: one-element device tensor); contiguous fp32."""
+    _req(x, torch.float32, "x"); _req(s, torch.float32, "s"); _req(out, torch.float32, "out")
+    if not (x.is_contiguous() and out.is_contiguous()) or x.numel() != out.numel() or s.numel() != 1:
+        raise ValueError("scale_by_scalar: contiguous tensors of equal size and a one-element scale required")
+    check(_lib.lib().sc_scale_by_scalar(x.data_ptr(), s.data_ptr(), out.data_ptr(), x.numel(), _stream()), "sc_scale_by_scalar")
+    return out
+
+
 def exp_scalar_bwd(y, dy, dx, mult: float = 1.0):
     check(_lib.lib().sc_exp_scalar_bwd(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), float(mult), _stream()),
           "sc_exp_scalar_bwd")

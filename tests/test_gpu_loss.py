@@ -46,6 +46,31 @@ def test_losses_w1_vs_reference_golden(golden_dir, tag):
         assert abs(float(res["d_scale"]) - float(z[f"{pre}_gscale"])) < 2e-6
 
 
+def test_single_process_head_and_loss_node_vs_reference_golden(golden_dir):
+    """Round 4: in a single process the head's GEMMs accumulate the gathered-feature terms onto the direct ones
+    (``join_local``: no ATen adds), and the loss node applies the upstream gradient with one ``sc_scale_by_scalar`` launch
+    over d_image | d_text | d_scale.  Both checked against the reference's own gradients (golden), the second through the
+    product's loss classes with an upstream gradient of 1 and of -2.5."""
+    C = _head()
+    from spatial_clip_amd import losses
+    z = load(golden_dir, "loss_w1_default.npz")
+    img, txt, s = z["img"].cuda(), z["txt"].cuda(), z["scale"].float().cuda()
+    res = C.contrastive_forward_backward(img, txt, s, mode="clip", join_local=True, want_recall=False)
+    assert "d_all" not in res and res["recall_hits"] is None
+    torch.testing.assert_close(res["d_image"].cpu(), z["cl_gimg"], atol=2e-6, rtol=1e-4)
+    torch.testing.assert_close(res["d_text"].cpu(), z["cl_gtxt"], atol=2e-6, rtol=1e-4)
+    for up in (1.0, -2.5):
+        a, b, sc = img.clone().requires_grad_(True), txt.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=float(z["cap"]) if float(z["cap"]) >= 0 else None,
+                                temp_reg_weight=float(z["w"]), neighbor_alpha_scale=0.5, float32_logits=True)
+        out = fn(a, b, sc, z["ids"].cuda(), z["ids"].cuda(), z["nb"].cuda(), z["alpha"].cuda())["contrastive_loss"]
+        assert abs(float(out) - float(z["spatial_loss"])) < 5e-6
+        (out * up).backward()
+        torch.testing.assert_close(a.grad.cpu(), up * z["sp_gimg"], atol=5e-6, rtol=1e-4)
+        torch.testing.assert_close(b.grad.cpu(), up * z["sp_gtxt"], atol=5e-6, rtol=1e-4)
+        assert abs(float(sc.grad) - up * float(z["sp_gscale"])) < 5e-6
+
+
 def test_losses_w2_emulated_ranks(golden_dir):
     """Each rank's loss / local grads for a 2-rank global batch, emulated on one GPU: the cross-rank
     d(all_features) terms are summed by hand exactly as the reduce-scatter would."""

@@ -104,18 +104,20 @@ def test_attention_fwd_persistent_vs_per_head_kernel(B, L, H, causal, q_rows, mo
     torch.testing.assert_close(outs[0][1][:, :, :nq], outs[1][1][:, :, :nq], atol=1e-4, rtol=1e-5)
 
 
-@pytest.mark.parametrize("path", ["persistent", "single_pass", "per_head"])
+@pytest.mark.parametrize("path", ["ring", "persistent", "single_pass", "per_head"])
 @pytest.mark.parametrize("B,L,H,causal", [(26, 197, 12, False), (40, 77, 8, True), (300, 33, 1, False), (9, 224, 30, True),
-                                          (3, 100, 2, False)])
+                                          (3, 100, 2, False), (70, 161, 12, False), (260, 64, 3, False), (25, 20, 12, False)])
 def test_attention_bwd_paths_walk_many_heads(B, L, H, causal, path, monkeypatch):
-    """The three backward kernels behind sc_attn_bwd (selected per call by SC_ATTN_BWD1 / SC_ATTN_BWD2):
-    single-pass (default; dQ summed over the key waves in an fp32 LDS accumulator, fixed order; non-causal only,
-    otherwise it declines and the next kernel runs), persistent two-pass with loader waves, one workgroup per head.
+    """The four backward kernels behind sc_attn_bwd (selected per call by SC_ATTN_BWD3 / SC_ATTN_BWD1 / SC_ATTN_BWD2):
+    ring (round 4, default: dS tiles in a three-block ring, dQ by one MFMA chain per block, rolling Q / dO refill;
+    non-causal only, otherwise it declines and the next kernel runs), single-pass (dQ summed over the key waves in an
+    fp32 LDS accumulator, fixed order; non-causal only), persistent two-pass with loader waves, one workgroup per head.
     More heads than CUs so that a persistent workgroup walks several heads; gradients against autograd and
     bit-identical across two launches (no float atomics)."""
     ops = _ops()
-    monkeypatch.setenv("SC_ATTN_BWD1", "1" if path == "single_pass" else "0")      # tried first
-    monkeypatch.setenv("SC_ATTN_BWD2", "1" if path == "persistent" else "0")       # tried second
+    monkeypatch.setenv("SC_ATTN_BWD3", "1" if path == "ring" else "0")             # tried first (round 4)
+    monkeypatch.setenv("SC_ATTN_BWD1", "1" if path == "single_pass" else "0")      # tried second
+    monkeypatch.setenv("SC_ATTN_BWD2", "1" if path == "persistent" else "0")       # tried third
     dh = 64
     d = H * dh
     g = torch.Generator().manual_seed(B * 7 + L)
