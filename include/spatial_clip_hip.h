@@ -60,6 +60,21 @@ long long sc_gemm_wgrad_ws_floats(int M, int N, int K, int splitk);
 int sc_gemm_wgrad_bias(const void* dY, int lddy, const void* X, int ldx, int M, int N, int K, float* dW, int ldw,
                        float* dbias, int splitk, float* ws, void* stream);
 
+/* Several weight (+ bias) gradients that share their reduction length K (the token axis of one transformer block) in ONE
+ * launch and one slab reduction: problem p is dW_p[M_p, N_p](f32, dense: ldw == N_p) = dY_p[K, M_p]^T . X_p[K, N_p] and,
+ * when dbias_p != NULL, dbias_p[M_p] = column sums of dY_p -- sc_gemm_wgrad_bias for up to SC_WGRAD_GROUP_MAX Linears
+ * (src/open_clip/transformer.py:253,260-264: in_proj, out_proj, c_fc, c_proj).  All problems run at the same split-K.
+ * ws: sc_gemm_wgrad_group_ws_floats() floats. */
+enum { SC_WGRAD_GROUP_MAX = 4 };
+typedef struct {
+    const void* dY; long long lddy;
+    const void* X; long long ldx;
+    float* dW; float* dbias;
+    int M; int N;
+} sc_wgrad_desc;
+long long sc_gemm_wgrad_group_ws_floats(const sc_wgrad_desc* descs, int n, int K, int splitk);
+int sc_gemm_wgrad_group(const sc_wgrad_desc* descs, int n, int K, int splitk, float* ws, void* stream);
+
 /* FP8 (OCP e4m3fn) forward GEMM of BASELINE configs[4] ("fp8 MFMA"; the reference has no fp8 path).  Recipe: every
  * operand ROW (token activations; weight output channel) is scaled by s = 2^floor(log2(448 / amax(row))) when it is
  * quantised (sc_quantize_rows_fp8 writes 1/s per row; fixed_scale > 0 skips the amax pass), the products accumulate in

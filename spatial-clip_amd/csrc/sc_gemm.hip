@@ -187,6 +187,43 @@ __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __rest
     }
 }
 
+// reduce_slabs_kernel for several (output, slabs) pairs in one launch: pair p owns blocks [first[p], first[p + 1])
+struct ReduceGroup {
+    float* out[SC_WGRAD_GROUP_MAX];
+    const float* slabs[SC_WGRAD_GROUP_MAX];        // null: the GEMM wrote `out` itself (split-K 1)
+    long long slab_stride[SC_WGRAD_GROUP_MAX];
+    long long n4[SC_WGRAD_GROUP_MAX];
+    float* cs_out[SC_WGRAD_GROUP_MAX];             // bias gradient, or null
+    const float* cs_part[SC_WGRAD_GROUP_MAX];
+    int cs_n[SC_WGRAD_GROUP_MAX];
+    int first[SC_WGRAD_GROUP_MAX + 1];
+    int n, nslab;
+};
+__global__ void reduce_slabs_group_kernel(const ReduceGroup r) {
+    int p = 0;
+    while (p + 1 < r.n && (int)blockIdx.x >= r.first[p + 1]) ++p;
+    const long long b = blockIdx.x - r.first[p], nb = r.first[p + 1] - r.first[p];
+    const float* slabs = r.slabs[p];
+    if (slabs != nullptr) {
+        float* out = r.out[p];
+        const long long stride = r.slab_stride[p], n4 = r.n4[p];
+        for (long long i = b * blockDim.x + threadIdx.x; i < n4; i += nb * blockDim.x) {
+            f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
+            for (int z = 1; z < r.nslab; ++z) s += reinterpret_cast<const f32x4*>(slabs + z * stride)[i];
+            reinterpret_cast<f32x4*>(out)[i] = s;
+        }
+    }
+    if (r.cs_out[p] != nullptr) {
+        const float* part = r.cs_part[p];
+        const int n = r.cs_n[p];
+        for (long long i = b * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) {
+            float s = 0.f;
+            for (int z = 0; z < r.nslab; ++z) s += part[(long long)z * n + i];
+            r.cs_out[p][i] = s;
+        }
+    }
+}
+
 template <int MODE, int EPI, bool KTAIL>
 int launch1(const GemmArgs& g, int nblocks, hipStream_t st) {
     static bool attr_done = false;
@@ -344,4 +381,93 @@ extern "C" int sc_gemm_wgrad_bias(const void* dY, int lddy, const void* X, int l
                           nullptr, 0, slab_floats ? splitk : 1, slab_floats ? slabs : nullptr, stream);
     if (rc != 0) return rc;
     return sc_colsum_bf16(dY, lddy, K, M, dbias, cs_part, stream);
+}
+
+
+// ---- several weight (+ bias) gradients over one token axis in one launch (include/spatial_clip_hip.h) ----
+static long long wgrad_group_layout(const sc_wgrad_desc* d, int n, int K, int splitk, long long* slab_off, long long* cs_off) {
+    // workspace = per problem [splitk slabs of M x N | splitk partial column sums of M], 16-float aligned; the plain
+    // per-problem path (sc_gemm_wgrad_bias) must fit too
+    long long off = 0, worst_single = 0;
+    const int sk = splitk < 1 ? 1 : splitk;
+    for (int p = 0; p < n; ++p) {
+        if (slab_off) slab_off[p] = off;
+        off += ((long long)sk * d[p].M * d[p].N + 15) / 16 * 16;
+        if (cs_off) cs_off[p] = off;
+        off += ((long long)sk * d[p].M + 15) / 16 * 16;
+        const long long single = sc_gemm_wgrad_ws_floats(d[p].M, d[p].N, K, splitk);
+        if (single > worst_single) worst_single = single;
+    }
+    return (off > worst_single ? off : worst_single) + 64;
+}
+
+extern "C" long long sc_gemm_wgrad_group_ws_floats(const sc_wgrad_desc* descs, int n, int K, int splitk) {
+    if (descs == nullptr || n < 1 || n > SC_WGRAD_GROUP_MAX) return 0;
+    return wgrad_group_layout(descs, n, K, splitk, nullptr, nullptr);
+}
+
+extern "C" int sc_gemm_wgrad_group(const sc_wgrad_desc* descs, int n, int K, int splitk, float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SC_CHECK(descs != nullptr && n >= 1 && n <= SC_WGRAD_GROUP_MAX, "sc_gemm_wgrad_group: 1..%d problems (n=%d)", SC_WGRAD_GROUP_MAX, n);
+    SC_CHECK(K > 0 && ws != nullptr, "sc_gemm_wgrad_group: K=%d, workspace required", K);
+    GemmArgs g[SC_WGRAD_GROUP_MAX];
+    for (int p = 0; p < n; ++p) {
+        const sc_wgrad_desc& d = descs[p];
+        SC_CHECK(d.M > 0 && d.N > 0 && (d.M % 4) == 0 && (d.N % 4) == 0 && d.dY && d.X && d.dW,
+                 "sc_gemm_wgrad_group: problem %d: bad shape M=%d N=%d", p, d.M, d.N);
+        SC_CHECK((d.lddy % 8) == 0 && (d.ldx % 8) == 0 && ((uintptr_t)d.dY % 16) == 0 && ((uintptr_t)d.X % 16) == 0 &&
+                 ((uintptr_t)d.dW % 16) == 0, "sc_gemm_wgrad_group: problem %d: operand alignment", p);
+        GemmArgs& a = g[p];
+        a.A = (const bf16*)d.dY; a.B = (const bf16*)d.X; a.M = d.M; a.N = d.N; a.K = K; a.lda = (int)d.lddy; a.ldb = (int)d.ldx;
+        a.C = d.dW; a.ldc = d.N; a.C2 = nullptr; a.ldc2 = 0; a.bias = nullptr; a.res = nullptr; a.ldres = 0;
+        a.aux = nullptr; a.ldaux = 0; a.tile_offset = 0; a.colsum = nullptr;
+    }
+    static const char* force = getenv("SC_GEMM_FORCE");
+    int sk = 1, kps = K;
+    if (!force && n > 1 && sc_gemm8p_tn_group_plan(g, n, splitk, &sk, &kps)) {
+        long long slab_off[SC_WGRAD_GROUP_MAX], cs_off[SC_WGRAD_GROUP_MAX];
+        (void)wgrad_group_layout(descs, n, K, sk, slab_off, cs_off);
+        ReduceGroup r;
+        r.n = n; r.nslab = sk;
+        int total = 0;
+        for (int p = 0; p < n; ++p) {
+            GemmArgs& a = g[p];
+            a.ntm = (a.M + 255) / 256; a.ntn = (a.N + 255) / 256;
+            a.splitk = sk; a.k_per_split = kps; a.slab_stride = 0;
+            if (sk > 1) { a.C = ws + slab_off[p]; a.slab_stride = (long long)a.M * a.N; }
+            a.colsum = descs[p].dbias ? ws + cs_off[p] : nullptr;
+            const long long n4 = (long long)a.M * a.N / 4;
+            int blocks = (int)((n4 + 255) / 256);
+            if (blocks > 1024) blocks = 1024;
+            r.out[p] = descs[p].dW; r.slabs[p] = sk > 1 ? ws + slab_off[p] : nullptr; r.slab_stride[p] = a.slab_stride;
+            r.n4[p] = n4; r.cs_out[p] = descs[p].dbias; r.cs_part[p] = ws + cs_off[p]; r.cs_n[p] = a.M;
+            r.first[p] = total;
+            total += blocks;
+        }
+        for (int p = n; p <= SC_WGRAD_GROUP_MAX; ++p) r.first[p] = total;
+        for (int p = n; p < SC_WGRAD_GROUP_MAX; ++p) { r.out[p] = nullptr; r.slabs[p] = nullptr; r.cs_out[p] = nullptr; }
+        const int rc = sc_gemm8p_tn_group_launch(g, n, st);
+        if (rc != 1) return rc < 0 ? rc : -1;
+        bool need = sk > 1;
+        for (int p = 0; p < n; ++p) need = need || descs[p].dbias != nullptr;
+        if (need) {
+            reduce_slabs_group_kernel<<<total, 256, 0, st>>>(r);
+            SC_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+    // outside the 256x256 kernel's range (toy shapes) or a single problem: one by one through the per-Linear entry points
+    for (int p = 0; p < n; ++p) {
+        const sc_wgrad_desc& d = descs[p];
+        int rc;
+        if (d.dbias) {
+            rc = sc_gemm_wgrad_bias(d.dY, (int)d.lddy, d.X, (int)d.ldx, d.M, d.N, K, d.dW, d.N, d.dbias, splitk, ws, stream);
+        } else {
+            const long long sf = sc_gemm_slab_floats(d.M, d.N, K, splitk);
+            rc = sc_gemm_bf16(SC_GEMM_TN, SC_EPI_F32, d.dY, (int)d.lddy, d.X, (int)d.ldx, d.M, d.N, K, d.dW, d.N, nullptr, 0,
+                              nullptr, nullptr, 0, nullptr, 0, sf ? splitk : 1, sf ? ws : nullptr, stream);
+        }
+        if (rc != 0) return rc;
+    }
+    return 0;
 }

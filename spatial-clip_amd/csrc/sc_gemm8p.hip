@@ -636,15 +636,14 @@ SC_DEVICE void ktile_tn(char* smem, unsigned lds0, const StagerTN& S, int t, con
     phase_tn<D, 4>(smem, lds0, S, t, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
 }
 
-__global__ __launch_bounds__(512, 2) void gemm8p_tn_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// one 256x256 output tile (or split-K slab tile) of the TN product described by g; idx = (z * ntm + tm) * ntn + tn
+SC_DEVICE void tn_tile(const GemmArgs& g, int idx, char* smem) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 15, lg = lane >> 4;
 
-    int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
     const int tn = idx % g.ntn;
     idx /= g.ntn;
     const int tm = idx % g.ntm;
@@ -738,6 +737,29 @@ __global__ __launch_bounds__(512, 2) void gemm8p_tn_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm8p_tn_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tn_tile(g, sc_xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+
+// Several weight gradients that share the reduction length (one Linear's token axis) in ONE launch: problem p owns the
+// remapped block ids [first[p], first[p + 1]).  Why (round 4): the four weight gradients of a transformer block were four
+// launches of about one round of workgroups each; out_proj (9 output tiles) needed split-K 28 to fill the chip -- 66 MB of
+// fp32 slabs for a 2.4 MB result and 28-K-tile workgroups that are mostly prologue and epilogue (820 TFLOP/s against
+// 1 100-1 190 for its siblings).  Grouped, every problem runs at the group's split-K.
+struct GemmGroup {
+    GemmArgs g[SC_WGRAD_GROUP_MAX];
+    int first[SC_WGRAD_GROUP_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(512, 2) void gemm8p_tn_group_kernel(const GemmGroup gg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
+    int p = 0;
+    while (p + 1 < gg.n && idx >= gg.first[p + 1]) ++p;
+    tn_tile(gg.g[p], idx - gg.first[p], smem);
 }
 
 int launch_tn(const GemmArgs& g, int nblocks, hipStream_t st) {
@@ -970,6 +992,46 @@ int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st) {
     if (epi == SC_EPI_GELU_GRAD_PAIR) return launch_f8<SC_EPI_GELU_GRAD_PAIR>(g, nblocks, st);
     if (epi == SC_EPI_BF16_MUL_AUX) return launch_f8<SC_EPI_BF16_MUL_AUX>(g, nblocks, st);
     return 0;
+}
+
+// Grouped TN launch (sc_gemm_wgrad_group): every g[p] describes dW_p[M_p, N_p] = A_p[K, M_p]^T . B_p[K, N_p] with the SAME K;
+// C / slab_stride / colsum are set by the caller for the split-K factor returned by sc_gemm8p_tn_group_plan.
+// 1 = launched, 0 = some problem is outside the 256x256 kernel's range (the caller runs the problems one by one).
+int sc_gemm8p_tn_group_plan(const GemmArgs* g, int n, int splitk_req, int* splitk_out, int* k_per_split) {
+    if (n < 1 || n > SC_WGRAD_GROUP_MAX) return 0;
+    const int K = g[0].K;
+    if ((K % BK) != 0) return 0;
+    for (int p = 0; p < n; ++p) {
+        if (g[p].K != K || g[p].M < 256 || g[p].N < 192 || (g[p].M % 8) != 0 || (g[p].N % 8) != 0) return 0;
+        if ((long long)g[p].M * g[p].N < 256LL * 256 * 8 || g[p].ldc != g[p].N) return 0;
+    }
+    const int ktiles = K / BK;
+    int splitk = splitk_req < 1 ? 1 : splitk_req;
+    if (splitk > ktiles) splitk = ktiles;
+    const int tiles_per = (ktiles + splitk - 1) / splitk;
+    *splitk_out = (ktiles + tiles_per - 1) / tiles_per;
+    *k_per_split = tiles_per * BK;
+    return 1;
+}
+int sc_gemm8p_tn_group_launch(const GemmArgs* g, int n, hipStream_t st) {
+    GemmGroup gg;
+    gg.n = n;
+    int total = 0;
+    for (int p = 0; p < n; ++p) {
+        gg.g[p] = g[p];
+        gg.first[p] = total;
+        total += g[p].ntm * g[p].ntn * g[p].splitk;
+    }
+    for (int p = n; p <= SC_WGRAD_GROUP_MAX; ++p) gg.first[p] = total;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_tn_group_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    gemm8p_tn_group_kernel<<<total, 512, LDS_BYTES, st>>>(gg);
+    SC_LAUNCH_CHECK();
+    return 1;
 }
 
 int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st) {

@@ -270,5 +270,8 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
 int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, float* c_final, hipStream_t st);
 // 256x256x64 phase-interleaved (ping-pong) kernel, NT only (sc_gemm8p.hip)
 int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
+// grouped TN launch of the same kernel (several weight gradients over one token axis): plan the common split-K, then launch
+int sc_gemm8p_tn_group_plan(const GemmArgs* g, int n, int splitk_req, int* splitk_out, int* k_per_split);
+int sc_gemm8p_tn_group_launch(const GemmArgs* g, int n, hipStream_t st);
 // fp8 (e4m3) NT variant of the same kernel; g.K / lda / ldb in 2-byte units, g.a_scale / g.b_scale set
 int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st);

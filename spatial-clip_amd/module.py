@@ -133,6 +133,14 @@ class SpatialClipLitModule(torch.nn.Module):
         ops.sgemm(f_i, D, 1, f_t, D, 1, z, B, B, B, D)
         return z * dict.__getitem__(output, "logit_scale").detach()
 
+    def root_gradient(self, loss: torch.Tensor) -> torch.Tensor:
+        """The 1.0 that ``loss.backward()`` would materialise with an ATen fill on every step, kept resident instead:
+        ``loss.backward(module.root_gradient(loss))`` leaves no ATen kernel in the training step."""
+        g = getattr(self, "_root_grad", None)
+        if g is None or g.device != loss.device or g.dtype != loss.dtype:
+            g = self._root_grad = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return g
+
     def training_step(self, batch: Dict[str, Any], batch_idx: int) -> torch.Tensor:
         output = self.model_step(batch, self.train_metrics)
         self.log("train/loss", output["loss"], on_step=True, on_epoch=True, prog_bar=True, sync_dist=True)

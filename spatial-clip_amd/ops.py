@@ -96,6 +96,45 @@ def gemm_wgrad_bias(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dbias: 
     check(rc, "sc_gemm_wgrad_bias")
 
 
+class _WgradDesc(ctypes.Structure):
+    """``sc_wgrad_desc`` of include/spatial_clip_hip.h."""
+    _fields_ = [("dY", ctypes.c_void_p), ("lddy", ctypes.c_longlong), ("X", ctypes.c_void_p), ("ldx", ctypes.c_longlong),
+                ("dW", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("M", ctypes.c_int), ("N", ctypes.c_int)]
+
+
+WGRAD_GROUP_MAX = 4
+
+
+def gemm_wgrad_group(problems, *, K: int, splitk: int = 1) -> None:
+    """Several weight (+ bias) gradients over ONE token axis in one launch: ``problems`` = iterable of
+    (dy [K, M], x [K, N], dw [M, N] fp32 dense, dbias [M] or None, M, N); dW = dY^T . X, dbias = column sums of dY."""
+    problems = list(problems)
+    if not 1 <= len(problems) <= WGRAD_GROUP_MAX:
+        raise ValueError(f"gemm_wgrad_group: 1..{WGRAD_GROUP_MAX} problems, got {len(problems)}")
+    arr = (_WgradDesc * len(problems))()
+    flops = 0.0
+    for d, (dy, x, dw, dbias, M, N) in zip(arr, problems):
+        _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw")
+        if dbias is not None: _req(dbias, torch.float32, "dbias")
+        if not dw.is_contiguous() or dw.numel() != M * N:
+            raise ValueError("gemm_wgrad_group: dw must be a dense [M, N] tensor")
+        d.dY, d.lddy, d.X, d.ldx = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+        d.dW, d.dbias, d.M, d.N = dw.data_ptr(), _ptr(dbias), M, N
+        flops += 2.0 * M * N * K
+    l = _lib.lib()
+    p = ctypes.cast(arr, ctypes.c_void_p)
+    ws = workspace(l.sc_gemm_wgrad_group_ws_floats(p, len(problems), K, splitk), problems[0][0].device, "wgrad")
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    rc = l.sc_gemm_wgrad_group(p, len(problems), K, splitk, ws.data_ptr(), _stream())
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append(("gemm_tn", flops, ev))
+    check(rc, "sc_gemm_wgrad_group")
+
+
 # bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream
 KERNEL_EVENTS = None
 

@@ -32,6 +32,31 @@ def _splitk_for(m_out: int, n_out: int, k: int) -> int:
     return max(1, min(want, 32))
 
 
+def _splitk_for_group(shapes, k: int, one_round: bool = False) -> int:
+    """Common split-K factor of a grouped weight-gradient launch: the smallest one that fills >= 95 % of whole rounds of
+    256 workgroups (256 CUs, one 256x256 tile each); ``one_round``: the largest one that stays within ONE round (the
+    weight gradients run beside the data-gradient chain: a launch of several rounds holds the chain's kernels back)."""
+    tiles = sum(((m + 255) // 256) * ((n + 255) // 256) for m, n in shapes)
+    ktiles = (k + 63) // 64
+    best = 1
+    for s in range(1, max(1, min(32, ktiles // 4)) + 1):
+        wg = tiles * s
+        if wg <= 256:
+            best = s
+        if not one_round and wg / (-(-wg // 256) * 256) >= 0.95:
+            return s
+    return best
+
+
+def _wgrad_group_mode() -> str:
+    """Read at every backward: SC_WGRAD_GROUP = 3 (default: the two weight gradients of each branch of a block in one
+    launch of at most ONE round of workgroups), 2 (the same with whole rounds filled: the MLP pair becomes two rounds),
+    1 (attention branch grouped only), 4 (all four of a block in one launch), 0 (one launch per Linear, rounds 1-3).
+    Same-box A/B, profiles/r04_wgrad_group_ab.txt: -0.06 ... -0.16 ms per step for 1 and 3, +0.2 ... +0.4 ms for the
+    multi-round launches of 2 and 4 on one box (they hold the data-gradient chain back)."""
+    return os.environ.get("SC_WGRAD_GROUP", "3")
+
+
 class _Bufs:
     """Named device buffers, (re)allocated when the requested shape changes."""
 
@@ -350,6 +375,7 @@ class TransformerStack:
             else:
                 ops.gemm(ops.NT, epi, g_bf, c.wb, out, M=M, N=N, K=K, **kw)
 
+        wg_mode = _wgrad_group_mode()
         dA = bf.get("dA", (M, d), BF16)
         dO = bf.get("dO", (M, d), BF16)
         delta = bf.get("delta", (B, H, L), F32)
@@ -386,7 +412,12 @@ class TransformerStack:
             dgrad(ops.EPI_BF16_MUL_AUX if self._u_holds_grad else ops.EPI_BF16_DGELU, g0, self._n(i, "mlp.c_proj.weight"), dU,
                   N=mlp, K=d, have_q8=g_has_q8, aux=u, q8kw=dq)
 
-            def w_mlp(g0=g0, h=h, dU=dU, a2=a2, g=g):
+            mlp_probs = [(g0, h, g("mlp.c_proj.weight"), None, d, mlp), (dU, a2, g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), mlp, d)]
+
+            def w_mlp(g0=g0, h=h, dU=dU, a2=a2, g=g, probs=mlp_probs):
+                if wg_mode in ("2", "3"):      # both weight gradients of the MLP branch in one launch + one slab reduction
+                    ops.gemm_wgrad_group(probs, K=M, splitk=_splitk_for_group([(d, mlp), (mlp, d)], M, one_round=wg_mode == "3"))
+                    return
                 ops.gemm(ops.TN, ops.EPI_F32, g0, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M, splitk=_splitk_for(d, mlp, M))
                 ops.gemm_wgrad_bias(dU, a2, g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), M=mlp, N=d, K=M,
                                     splitk=_splitk_for(mlp, d, M))
@@ -396,7 +427,8 @@ class TransformerStack:
                 before_write(a2)
                 ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
                                   bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32), M, d)
-            on_side(w_mlp, (g0, dU, h, a2) if self.recompute else (g0, dU))
+            if wg_mode != "4":
+                on_side(w_mlp, (g0, dU, h, a2) if self.recompute else (g0, dU))
             cfc = cp("mlp.c_fc.weight")
             if dU_has_q8 and cfc.wb8 is not None:
                 ops.gemm_fp8(ops.EPI_BF16, dU8, self._dq_scale_inv[2 * i + 1:2 * i + 2], cfc.wb8, cfc.wb8s, dA, M=M, N=d, K=mlp,
@@ -414,7 +446,16 @@ class TransformerStack:
             before_write(dqkv)
             ops.attn_bwd(qkv, o, dO, lse, B, L, H, dh, self.causal, dqkv=dqkv, delta=delta)
 
-            def w_attn(g1=g1, o=o, dqkv=dqkv, a1=a1, g=g):
+            attn_probs = [(g1, o, g("attn.out_proj.weight"), None, d, d),
+                          (dqkv, a1, g("attn.in_proj_weight"), g("attn.in_proj_bias"), 3 * d, d)]
+
+            def w_attn(g1=g1, o=o, dqkv=dqkv, a1=a1, g=g, probs=attn_probs, more=mlp_probs):
+                if wg_mode == "4":      # all four weight gradients of the block in one launch
+                    ops.gemm_wgrad_group(more + probs, K=M, splitk=_splitk_for_group([(d, mlp), (mlp, d), (d, d), (3 * d, d)], M))
+                    return
+                if wg_mode in ("1", "2", "3"):      # out_proj (9 tiles) no longer needs split-K 28 to fill the chip
+                    ops.gemm_wgrad_group(probs, K=M, splitk=_splitk_for_group([(d, d), (3 * d, d)], M))
+                    return
                 ops.gemm(ops.TN, ops.EPI_F32, g1, o, g("attn.out_proj.weight"), M=d, N=d, K=M, splitk=_splitk_for(d, d, M))
                 ops.gemm_wgrad_bias(dqkv, a1, g("attn.in_proj_weight"), g("attn.in_proj_bias"), M=3 * d, N=d, K=M,
                                     splitk=_splitk_for(3 * d, d, M))
@@ -422,7 +463,10 @@ class TransformerStack:
                 before_write(a1)
                 ops.layernorm_fwd(self.x_in[i], s.p(self._n(i, "ln_1.weight")), s.p(self._n(i, "ln_1.bias")), a1,
                                   bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32), M, d)
-            on_side(w_attn, (g1, dqkv, a1) if self.recompute else (g1, dqkv))
+            reads = (g1, dqkv, a1) if self.recompute else (g1, dqkv)
+            if wg_mode == "4":
+                reads = reads + ((g0, dU, h, a2) if self.recompute else (g0, dU))
+            on_side(w_attn, reads)
             ops.gemm(ops.NT, ops.EPI_BF16, dqkv, cp("attn.in_proj_weight").wb, dA, M=M, N=d, K=3 * d)
             # LN1 backward; its column sum is the previous block's c_proj.bias gradient
             prev_bias = s.g(self._n(i - 1, "mlp.c_proj.bias")) if i > 0 else None

@@ -204,7 +204,7 @@ class Trainer:
                 batch = _to_device(batch, model.device)
                 with streams.chain_stream():
                     loss = model.training_step(batch, i)
-                    loss.backward()
+                    loss.backward(model.root_gradient(loss))
                     reducer.finish()
                     opt.step(grad_scale=1.0 / W, max_norm=self.gradient_clip_val)
                 if sched is not None:

@@ -246,3 +246,33 @@ def test_wgrad_with_fused_bias_grad(M, N, K, splitk):
     ops.gemm_wgrad_bias(dy.cuda(), x.cuda(), dw, db, M=M, N=N, K=K, splitk=splitk)
     torch.testing.assert_close(dw.cpu(), dy.float().t() @ x.float(), atol=2e-3 * max(1, K ** 0.5 / 8), rtol=2e-3)
     torch.testing.assert_close(db.cpu(), dy.float().sum(0), atol=2e-3 * max(1, K ** 0.5 / 8), rtol=1e-4)
+
+
+@pytest.mark.parametrize("K,splitk,shapes", [
+    (64 * 13, 4, [(768, 768, False), (2304, 768, True)]),                       # out_proj + in_proj of a ViT-B block
+    (64 * 9, 3, [(768, 3072, False), (3072, 768, True)]),                       # c_proj + c_fc
+    (64 * 7, 7, [(768, 1024, False), (1024, 768, True), (512, 512, False), (1536, 512, True)]),   # four at once
+    (64 * 5, 1, [(512, 512, True), (256, 768, True)]),                          # split-K 1: no slabs, bias sums only
+    (200, 2, [(64, 64, True), (128, 64, False)]),                               # toy shapes: per-Linear fallback
+    (64 * 6, 2, [(1024, 512, True)]),                                           # a group of one
+])
+def test_wgrad_group_exact(K, splitk, shapes):
+    """sc_gemm_wgrad_group: several weight (+ bias) gradients over one token axis in ONE launch + one slab reduction
+    (round 4).  Small-integer operands make every sum exact: each problem must equal dY^T . X and the column sums of dY
+    bit for bit, whatever the group's common split-K, and must not touch the other problems' outputs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(K + len(shapes))
+    for rep in range(2):
+        probs, want = [], []
+        for (M, N, bias) in shapes:
+            dy = torch.randint(-3, 4, (K, M), generator=g).to(torch.bfloat16)
+            x = torch.randint(-3, 4, (K, N), generator=g).to(torch.bfloat16)
+            dw = torch.full((M, N), 9.0, dtype=torch.float32, device="cuda")
+            db = torch.full((M,), 9.0, dtype=torch.float32, device="cuda") if bias else None
+            probs.append((dy.cuda(), x.cuda(), dw, db, M, N))
+            want.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+        ops.gemm_wgrad_group(probs, K=K, splitk=splitk)
+        for (dyd, xd, dw, db, M, N), (w, b) in zip(probs, want):
+            assert torch.equal(dw.cpu(), w), (K, splitk, M, N, rep)
+            if db is not None:
+                assert torch.equal(db.cpu(), b), (K, splitk, M, N, rep, "bias")

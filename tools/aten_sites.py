@@ -47,7 +47,7 @@ def main():
     def step(i):
         with streams.chain_stream():
             loss = m.training_step(batches[i % 2], i)
-            loss.backward()
+            loss.backward(m.root_gradient(loss))
             reducer.finish()
             opt.step(grad_scale=1.0, max_norm=1.0)
             sched.step()
