@@ -97,6 +97,11 @@ int sc_gemm_fp8_q(int epi, const void* A8, int lda, const float* a_scale_inv, in
                   const void* res, int ldres, const void* aux, int ldaux, void* q8_out, long long ldq8,
                   const float* q8_scale, float* q8_amax, void* stream);
 int sc_fp8_scale_update(float* amax_slots, float* scale, float* scale_inv, int n, int margin_bits, void* stream);
+/* The same with an amax history: this step's maxima are stored in hist[slot][n] (slot = step % hist_len, owned by the
+ * caller) and the scales follow the maximum over all hist_len rows -- a quiet step does not expose the next one to the
+ * saturating clamp. */
+int sc_fp8_scale_update_hist(float* amax_slots, float* hist, int hist_len, int slot, float* scale, float* scale_inv, int n,
+                             int margin_bits, void* stream);
 /* The quantiser fused into the kernels that hold a complete row (round 3): LayerNorm forward also emits the e4m3 copy
  * of its output (A operand of the qkv / c_fc forward GEMMs), LayerNorm backward the e4m3 copy of the new residual
  * gradient (A operand of the c_proj / out_proj data-gradient GEMMs; SC_EPI_BF16_DGELU takes aux = the pre-GELU tensor),

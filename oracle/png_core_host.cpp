@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE: the DEFLATE / PNG core of the device decoder (spatial-clip_amd/csrc/sc_png_core.h) compiled for the
 // CPU with plain-array IO, so that tests/test_cpu_png.py can check the bit-stream logic against PIL / zlib on the build
 // machine.  The product path never links this file (the device kernel instantiates the same header in sc_png.hip).
-//   g++ -O2 -shared -fPIC -o oracle/_ref/libpngcore.so oracle/png_core_host.cpp
+//   g++ -O2 -shared -fPIC -o oracle/_host/libpngcore.so oracle/png_core_host.cpp
 #include "../spatial-clip_amd/csrc/sc_png_core.h"
 #include <stdlib.h>
 #include <string.h>

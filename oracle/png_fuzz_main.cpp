@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE: runs the CPU build of the PNG / DEFLATE core (png_core_host.cpp) over every file named on the command
 // line and prints one status per file.  tests/test_cpu_png.py compiles this with -fsanitize=address,undefined and feeds it
 // damaged files: every one must come back with a status (0 or an error code), never with a sanitizer report.
-//   g++ -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -o oracle/_ref/png_fuzz oracle/png_fuzz_main.cpp
+//   g++ -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -o oracle/_host/png_fuzz oracle/png_fuzz_main.cpp
 #include "png_core_host.cpp"
 #include <stdio.h>
 #include <vector>

@@ -193,6 +193,17 @@ def broadcast_flag(flag: bool, src: int = 0) -> bool:
     return bool(int(t.cpu()[0]))
 
 
+def broadcast_flag_and_value(flag: bool, value: float, src: int = 0):
+    """Rank ``src``'s (decision, score) for everybody -- one float64 collective.  The best-checkpoint bookkeeping must
+    compare later epochs against the SAME best score on every rank, also when the monitored value is rank-local."""
+    if not is_dist():
+        return bool(flag), float(value)
+    t = torch.tensor([1.0 if flag else 0.0, float(value)], dtype=torch.float64, device=_scalar_device())
+    dist.broadcast(t, src=src)
+    t = t.cpu()
+    return bool(t[0] != 0.0), float(t[1])
+
+
 # ---------------------------------------------------------------------------------------------- packing
 def _pack(feat: torch.Tensor, ids_a: Optional[torch.Tensor], ids_b: Optional[torch.Tensor], out: torch.Tensor) -> None:
     """out[B, D (+4)] = feat | ids_a (int64 as 2 floats) | ids_b.  Device tensors take the HIP pack kernel."""

@@ -91,7 +91,39 @@ __global__ void fp8_scale_update_kernel(float* __restrict__ amax_slots, float* _
     }
 }
 
+// The same with a short history (advisor, round 3): this step's maximum goes to hist[slot][t] and the scale is taken from the
+// maximum over all hist_len recorded steps, so that one quiet step does not leave the next, louder one to the clamp at +-448.
+__global__ void fp8_scale_update_hist_kernel(float* __restrict__ amax_slots, float* __restrict__ hist, int hist_len, int slot,
+                                             float* __restrict__ scale, float* __restrict__ scale_inv, int n, int margin_bits) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float amax = 0.f;
+    for (int k = 0; k < 64; ++k) {
+        amax = fmaxf(amax, amax_slots[t * 64 + k]);
+        amax_slots[t * 64 + k] = 0.f;
+    }
+    if (!(amax < 3.0e38f)) amax = 0.f;          // inf / nan maxima are not history
+    hist[(long long)slot * n + t] = amax;
+    float hmax = 0.f;
+    for (int k = 0; k < hist_len; ++k) hmax = fmaxf(hmax, hist[(long long)k * n + t]);
+    if (hmax > 0.f) {
+        const float s = exp2f(floorf(log2f(448.0f / hmax)) - (float)margin_bits);
+        scale[t] = s;
+        scale_inv[t] = 1.0f / s;
+    }
+}
+
 }  // namespace
+
+extern "C" int sc_fp8_scale_update_hist(float* amax_slots, float* hist, int hist_len, int slot, float* scale, float* scale_inv,
+                                        int n, int margin_bits, void* stream) {
+    SC_CHECK(n > 0 && amax_slots && hist && scale && scale_inv && hist_len >= 1 && hist_len <= 64 && slot >= 0 && slot < hist_len &&
+             margin_bits >= 0 && margin_bits <= 8, "sc_fp8_scale_update_hist: bad arguments");
+    fp8_scale_update_hist_kernel<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(amax_slots, hist, hist_len, slot, scale, scale_inv, n,
+                                                                                margin_bits);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int sc_fp8_scale_update(float* amax_slots, float* scale, float* scale_inv, int n, int margin_bits, void* stream) {
     SC_CHECK(n > 0 && amax_slots && scale && scale_inv && margin_bits >= 0 && margin_bits <= 8, "sc_fp8_scale_update: bad arguments");

@@ -193,12 +193,24 @@ class SpatialClipNet(torch.nn.Module):
             if stack is not None:
                 stack.set_grad_checkpointing(enable)
 
+    def _stacks(self):
+        return [(name, t.stack) for name, t in (("vision", self.vision), ("second", self.second)) if getattr(t, "stack", None) is not None]
+
     def reset_fp8_scaling(self) -> None:
-        """fp8 path: drop the per-tensor scales carried from the previous step (towers.TransformerStack.reset_fp8_scaling)."""
-        for tower in (self.vision, self.second):
-            stack = getattr(tower, "stack", None)
-            if stack is not None:
-                stack.reset_fp8_scaling()
+        """fp8 path: drop the per-tensor scales carried from the previous steps (towers.TransformerStack.reset_fp8_scaling)."""
+        for _, stack in self._stacks():
+            stack.reset_fp8_scaling()
+
+    def fp8_scaling_state(self) -> Optional[Dict[str, Any]]:
+        """Delayed-scaling state of both towers for a checkpoint (None off the fp8 path)."""
+        if self.precision != "fp8":
+            return None
+        return {name: stack.fp8_scaling_state() for name, stack in self._stacks()}
+
+    def load_fp8_scaling_state(self, state: Optional[Dict[str, Any]]) -> None:
+        """Restore what fp8_scaling_state() saved; anything missing or mismatched resets that tower's history instead."""
+        for name, stack in self._stacks():
+            stack.load_fp8_scaling_state((state or {}).get(name))
 
     def _load_pretrained(self, pretrained: str) -> None:
         if os.path.isfile(pretrained):        # local checkpoint path branch of factory.py:418-421
@@ -258,6 +270,7 @@ class SpatialClipNet(torch.nn.Module):
             print(f"[spatial_clip_amd] {source}: loaded {len(matched)} tensors; left at init: {len(missing)} "
                   f"(e.g. {missing[:2]}); unused checkpoint keys: {len(unexpected)} (e.g. {unexpected[:2]})")
         self.store.load_state_dict(matched, strict=False)
+        self.reset_fp8_scaling()            # new weights: the delayed e4m3 scales of the old ones are not history for them
         return {"missing": missing, "unexpected": unexpected}
 
     def state_dict(self, *a, **k) -> Dict[str, torch.Tensor]:
@@ -265,9 +278,13 @@ class SpatialClipNet(torch.nn.Module):
 
     def load_state_dict(self, sd, strict: bool = True):
         self.store.load_state_dict(sd, strict=strict)
+        self.reset_fp8_scaling()
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, images: torch.Tensor, texts: torch.Tensor) -> Dict[str, torch.Tensor]:
+        train_pass = torch.is_grad_enabled()        # read HERE: inside autograd.Function.forward grad mode is always off
+        for _, stack in self._stacks():
+            stack.fp8_train_pass = train_pass
         img, txt, s = _NetFn.apply(self.store.params["logit_scale"], self, images, texts)
         return {"image_features": img, "text_features": txt, "logit_scale": s, "logit_bias": None}
 

@@ -578,12 +578,22 @@ def quantize_rows_fp8(src: torch.Tensor, dst: Optional[torch.Tensor] = None, sca
     return dst, scale_inv
 
 
-def fp8_scale_update(amax_slots: torch.Tensor, scale: torch.Tensor, scale_inv: torch.Tensor, margin_bits: int = 1) -> None:
-    """Delayed scaling: next step's per-tensor e4m3 scales from the maxima the epilogues recorded ([n, 64] slots, cleared)."""
+def fp8_scale_update(amax_slots: torch.Tensor, scale: torch.Tensor, scale_inv: torch.Tensor, margin_bits: int = 1,
+                     hist: Optional[torch.Tensor] = None, slot: int = 0) -> None:
+    """Delayed scaling: next step's per-tensor e4m3 scales from the maxima the epilogues recorded ([n, 64] slots, cleared).
+    ``hist`` (fp32 [H, n]) + ``slot``: keep the maxima of the last H steps and scale for their maximum."""
     _req(amax_slots, torch.float32, "amax_slots"); _req(scale, torch.float32, "scale"); _req(scale_inv, torch.float32, "scale_inv")
     n = scale.numel()
     if amax_slots.numel() != n * 64 or scale_inv.numel() != n:
         raise ValueError("fp8_scale_update: amax_slots must be [n, 64] for n scales")
+    if hist is not None:
+        _req(hist, torch.float32, "hist")
+        if hist.dim() != 2 or hist.shape[1] != n or not hist.is_contiguous():
+            raise ValueError("fp8_scale_update: hist must be a contiguous [H, n] tensor")
+        check(_lib.lib().sc_fp8_scale_update_hist(amax_slots.data_ptr(), hist.data_ptr(), hist.shape[0], int(slot) % hist.shape[0],
+                                                  scale.data_ptr(), scale_inv.data_ptr(), n, int(margin_bits), _stream()),
+              "sc_fp8_scale_update_hist")
+        return
     check(_lib.lib().sc_fp8_scale_update(amax_slots.data_ptr(), scale.data_ptr(), scale_inv.data_ptr(), n, int(margin_bits),
                                          _stream()), "sc_fp8_scale_update")
 

@@ -89,11 +89,25 @@ class ShardIndex:
 
     # ---- the batch producer's forms: one descriptor per tar for the life of the index, PNG bytes read straight into the
     # (pinned) staging buffer, sentences read once
+    # At most MAX_OPEN_TARS descriptors are kept (least recently used closed first): a corpus with more tars than the
+    # process's RLIMIT_NOFILE (1024 by default; train / val / test indices each hold their own set) must not die with
+    # EMFILE in the middle of an epoch.  The sentence cache is bounded the same way (MAX_CACHED_TEXTS entries).
+    MAX_OPEN_TARS = 128
+    MAX_CACHED_TEXTS = 1 << 18
+
     def _fd(self, tar: str) -> int:
-        fds = self.__dict__.setdefault("_fds", {})
+        fds = self.__dict__.get("_fds")
+        if fds is None:
+            import collections
+            fds = self.__dict__["_fds"] = collections.OrderedDict()
         fd = fds.get(tar)
         if fd is None:
+            while len(fds) >= self.MAX_OPEN_TARS:
+                _, old = fds.popitem(last=False)
+                os.close(old)
             fd = fds[tar] = os.open(tar, os.O_RDONLY)
+        else:
+            fds.move_to_end(tar)
         return fd
 
     def png_size(self, i: int) -> int:
@@ -110,7 +124,10 @@ class ShardIndex:
         t = cache.get(i)
         if t is None:
             e = self.entries[i]
-            t = cache[i] = os.pread(self._fd(e["tar"]), e["txt"][1], e["txt"][0]).decode("utf-8")
+            t = os.pread(self._fd(e["tar"]), e["txt"][1], e["txt"][0]).decode("utf-8")
+            if len(cache) >= self.MAX_CACHED_TEXTS:
+                cache.clear()                  # bounded: a corpus larger than the cap is simply re-read
+            cache[i] = t
         return t
 
     def close(self) -> None:
@@ -406,7 +423,9 @@ class ShardedSpatialDataModule:
                     blob = host[:total].to(dev, non_blocking=True)
                     ring.copied(cur)
                     tiles_all, status = ops.png_decode(blob, torch.from_numpy(offsets).to(dev), self.image_size, self.image_size)
-                    for j in torch.nonzero(status != 0).flatten().cpu().tolist():       # declined by the kernel: PIL
+                    # tiles the kernel declined go to PIL before the augmentation reads them: one readback per GROUP, on the
+                    # producer thread and its own stream (the training thread never waits for it)
+                    for j in torch.nonzero(status != 0).flatten().cpu().tolist():
                         tiles_all[j] = torch.from_numpy(decode_png(bytes(mv[offsets[j]:offsets[j + 1]]), self.image_size)).to(dev)
                 at = 0
                 for idx in group:
@@ -435,9 +454,12 @@ class ShardedSpatialDataModule:
             for batch, _ in self._produce(name, train, dev, None):
                 yield batch
             return
-        side = self.__dict__.get("_side")
+        # one producer stream PER SPLIT: an in-epoch validation must not queue behind the decode / augmentation work the
+        # training producer has already enqueued (up to decode_ahead batches) on a shared stream (advisor, round 3)
+        sides = self.__dict__.setdefault("_side_streams", {})
+        side = sides.get(name)
         if side is None:
-            side = self._side = torch.cuda.Stream(device=dev)
+            side = sides[name] = torch.cuda.Stream(device=dev)
         q: "queue.Queue[Any]" = queue.Queue(maxsize=2 * self.decode_ahead)
         stop = threading.Event()
 

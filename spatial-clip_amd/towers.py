@@ -102,23 +102,52 @@ class TransformerStack:
         # previous step; tensor 2 i = h of block i, 2 i + 1 = dU of block i.  Not "ready" until one backward has run.
         self._dq_ready = False
         self._dq_on = os.environ.get("SC_FP8_DELAYED", "1") != "0"      # A/B switch: 0 keeps h / dU consumers in bf16
+        # a forward whose backward will run (grad mode on: set by SpatialClipNet.forward) records maxima and may consume the
+        # delayed scales; evaluation forwards (validation, test, zero-shot bank) do neither: they run the h consumer in bf16, so
+        # a fresh eval process and an in-fit validation of the same weights give the same numbers (advisor, round 3)
+        self.fp8_train_pass = True
+        self._dq_step = 0
         if self.fp8:
             n = 2 * layers
             self._dq_scale = torch.zeros(n, dtype=F32, device=store.device)
             self._dq_scale_inv = torch.ones(n, dtype=F32, device=store.device)
             self._dq_amax = torch.zeros((n, 64), dtype=F32, device=store.device)
+            self._dq_hist = torch.zeros((self.FP8_AMAX_HISTORY, n), dtype=F32, device=store.device)
+
+    FP8_AMAX_HISTORY = 4        # steps of per-tensor maxima the delayed scales are taken over
 
     def set_grad_checkpointing(self, enable: bool = True) -> None:
         self.recompute = bool(enable)
 
     def reset_fp8_scaling(self) -> None:
         """Forget the delayed-scaling history (the next step runs the h / dU consumers in bf16 and records fresh maxima):
-        the fp8 path is a function of (weights, batch, scales of the previous step)."""
+        the fp8 path is a function of (weights, batch, scales of the previous steps).  Called whenever the weights are
+        replaced (load_state_dict, checkpoint load without saved scales)."""
         self._dq_ready = False
+        self._dq_step = 0
         if self.fp8:
             self._dq_scale.zero_()
             self._dq_scale_inv.fill_(1.0)
             self._dq_amax.zero_()
+            self._dq_hist.zero_()
+
+    def fp8_scaling_state(self) -> Optional[Dict[str, object]]:
+        """The delayed-scaling state as host tensors (checkpointed beside the weights: a resumed run continues with the
+        scales it stopped with), or None off the fp8 path."""
+        if not self.fp8:
+            return None
+        return {"scale": self._dq_scale.cpu(), "scale_inv": self._dq_scale_inv.cpu(), "hist": self._dq_hist.cpu(),
+                "ready": bool(self._dq_ready), "step": int(self._dq_step)}
+
+    def load_fp8_scaling_state(self, st: Optional[Dict[str, object]]) -> None:
+        self.reset_fp8_scaling()
+        if not self.fp8 or not st or tuple(st["scale"].shape) != tuple(self._dq_scale.shape) \
+                or tuple(st["hist"].shape) != tuple(self._dq_hist.shape):
+            return
+        self._dq_scale.copy_(st["scale"])
+        self._dq_scale_inv.copy_(st["scale_inv"])
+        self._dq_hist.copy_(st["hist"])
+        self._dq_ready, self._dq_step = bool(st["ready"]), int(st["step"])
 
     def _act(self, kind: str, i: int, shape) -> torch.Tensor:
         """Buffer of a block's recomputable activation (a1 / a2 / h): one per block, or two rotating ones in
@@ -196,7 +225,7 @@ class TransformerStack:
             epi_gelu = ops.EPI_GELU_PAIR if self.recompute else ops.EPI_GELU_GRAD_PAIR
             self._u_holds_grad = not self.recompute        # what THIS forward left in the u buffers (read by backward)
             hq = None
-            if self.fp8 and self._dq_on:      # the GELU epilogue also emits e4m3(h) with last step's scale + records max|h|
+            if self.fp8 and self._dq_on and self.fp8_train_pass:      # the GELU epilogue also emits e4m3(h) with last step's scale + records max|h|
                 h8 = bf.get("q8.h", (M, mlp), torch.uint8)
                 hq = dict(q8_out=h8, q8_scale=self._dq_scale[2 * i:2 * i + 1], q8_amax=self._dq_amax[2 * i])
             self._linear_fwd(epi_gelu, a2, self._n(i, "mlp.c_fc.weight"), u,
@@ -478,8 +507,10 @@ class TransformerStack:
             g_has_q8 = qg is not None
             if on_layer_done is not None:
                 on_side(lambda i=i: on_layer_done(i), ())     # the bucket all-reduce follows the side stream
-        if self.fp8 and self._dq_on:          # next step's per-tensor scales from this step's recorded maxima
-            ops.fp8_scale_update(self._dq_amax, self._dq_scale, self._dq_scale_inv, margin_bits=1)
+        if self.fp8 and self._dq_on:          # next step's per-tensor scales from the maxima of the last FP8_AMAX_HISTORY steps
+            ops.fp8_scale_update(self._dq_amax, self._dq_scale, self._dq_scale_inv, margin_bits=1, hist=self._dq_hist,
+                                 slot=self._dq_step % self.FP8_AMAX_HISTORY)
+            self._dq_step += 1
             self._dq_ready = True
         if overlap:
             ev = torch.cuda.Event()

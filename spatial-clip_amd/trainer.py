@@ -253,7 +253,9 @@ class Trainer:
     def _checkpoint_epoch(self, model, opt, sched, rec: Dict[str, Any]) -> None:
         """Best / last bookkeeping runs on EVERY rank (Lightning broadcasts ``best_model_path``: src/train.py:122-128
         reads it back on all ranks for ``trainer.test(ckpt_path=...)``); only the file writes / removals are rank 0's.
-        The paths are deterministic and the score is rank 0's, broadcast, so every rank names the same file."""
+        The paths are deterministic and BOTH the decision and the score are rank 0's, broadcast together (one float64
+        collective), so every rank names the same file and compares later epochs against the same best score -- also with a
+        rank-local monitor (advisor, round 3: only the flag used to travel)."""
         cb = self.checkpoint_callback
         if cb is None:
             return
@@ -264,8 +266,9 @@ class Trainer:
         cb.last_model_path = last
         score = rec.get(cb.monitor)
         improved = isinstance(score, float) and cb.is_better(score)
-        improved = comm.broadcast_flag(improved, src=0)
+        improved, score0 = comm.broadcast_flag_and_value(improved, score if isinstance(score, float) else float("nan"), src=0)
         if improved:
+            score = score0
             best = os.path.join(cb.dirpath, f"epoch_{int(rec['epoch']):03d}.ckpt")
             if self.is_global_zero:
                 self.save_checkpoint(best, model, opt, sched, self.global_step)
@@ -284,6 +287,9 @@ class Trainer:
             ck["optimizer"] = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in optimizer.state_dict().items()}
         if scheduler is not None:
             ck["scheduler_last_epoch"] = scheduler.last_epoch
+        fp8 = model.net.fp8_scaling_state() if hasattr(model.net, "fp8_scaling_state") else None
+        if fp8 is not None:
+            ck["fp8_scaling"] = fp8         # delayed e4m3 scales + amax history: a resumed run continues with them
         torch.save(ck, path)
 
     @staticmethod
@@ -291,7 +297,9 @@ class Trainer:
         """Accepts this trainer's files and the reference's Lightning / DDP / plain-CLIP layouts (key prefixes
         ``net.model.``, ``module.`` are stripped: net.strip_checkpoint_prefix)."""
         ck = torch.load(path, map_location="cpu", weights_only=False)
-        model.net.load_checkpoint_state_dict(ck, source=path)
+        model.net.load_checkpoint_state_dict(ck, source=path)          # resets the fp8 scaling history ...
+        if hasattr(model.net, "load_fp8_scaling_state"):
+            model.net.load_fp8_scaling_state(ck.get("fp8_scaling"))     # ... and restores it when the file carries one
         if optimizer is not None and isinstance(ck.get("optimizer"), dict) and "exp_avg" in ck["optimizer"]:
             optimizer.load_state_dict({k: (v.to(model.device) if isinstance(v, torch.Tensor) else v)
                                        for k, v in ck["optimizer"].items()})

@@ -143,6 +143,9 @@ class _StubNet:
     def state_dict(self):
         return {"w": torch.zeros(2)}
 
+    def fp8_scaling_state(self):
+        return None
+
 
 class _StubModel:
     net = _StubNet()
@@ -171,9 +174,11 @@ def _scalar_worker(rank, world, port, tmp, ret):
     for epoch, v in enumerate([(1.0, 1.0), (2.0, 0.5), (3.0, 0.2)]):
         stops.append(tr._early_stop({"epoch": epoch, "val/loss": v[rank]}))
     out["stops"] = stops
-    # checkpoint bookkeeping runs on every rank; only rank 0 writes
-    for epoch, score in enumerate([0.1, 0.3, 0.2]):
-        tr._checkpoint_epoch(model, None, None, {"epoch": epoch, "val/R@1": score})
+    # checkpoint bookkeeping runs on every rank; only rank 0 writes.  The monitored scores DISAGREE between the ranks (a
+    # rank-local monitor): rank 0's decision AND score are what every rank must end up with (0.3 at epoch 1; rank 1's own
+    # 0.9 at epoch 2 must not make it the best there, nor leave 0.9 behind as the score later epochs compare against)
+    for epoch, score in enumerate([(0.1, 0.05), (0.3, 0.1), (0.2, 0.9)]):
+        tr._checkpoint_epoch(model, None, None, {"epoch": epoch, "val/R@1": score[rank]})
     cb = tr.checkpoint_callback
     out["best"], out["last"], out["score"] = cb.best_model_path, cb.last_model_path, cb.best_model_score
     out["files"] = sorted(os.listdir(cb.dirpath))

@@ -65,9 +65,13 @@ def test_instantiate_partials_and_targets(monkeypatch):
 
 @pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("exp", ["smoke_shards", "medium_normal", "medium_spatial", "spatial_v1",
-                                 "spatial_v2_multi_gpu", "smoke_hugo"])
+                                 "spatial_v2_multi_gpu", "smoke_hugo", "compare_hugo_overlap", "compare_medium_overlap",
+                                 "smoke_multitech", "spatial_v3_multigpu_moreepochs"])
 def test_reference_config_tree_composes(exp, monkeypatch):
-    """The reference's OWN configs/ directory drives the composer; its missing data group falls back to ours."""
+    """The reference's OWN configs/ directory drives the composer; its missing data group falls back to ours.  All ten
+    files of the reference's configs/experiment/ (the parametrisation is checked against the directory listing)."""
+    have = sorted(f[:-5] for f in os.listdir(os.path.join(REF_CONFIGS, "experiment")) if f.endswith(".yaml"))
+    assert exp in have and len(have) == 10, have
     monkeypatch.setenv("PROJECT_ROOT", "/tmp/proj")
     cfg = H.compose("train.yaml", [f"experiment={exp}", "logger=csv"], config_dir=REF_CONFIGS)
     assert cfg.model._target_ == "src.models.spatial_clip_module.SpatialClipLitModule"

@@ -169,7 +169,9 @@ def _vitl_genetr(precision, seed=0, lr=3e-4, recompute=False):
 
 # stated bounds against the fp32 oracle on identical weights and batch: the north-star's for the bf16-mixed policy, this
 # build's own for e4m3 GEMM operands (bench.py prints the same pair as LOSS_TOLERANCE / FEATURE_TOLERANCE)
-CFG4_BOUNDS = {"bf16": (1e-3, 5e-3), "fp8": (1e-2, 4e-2)}
+# round 4: the e4m3 pair is stated at what five runs measured plus margin (|d loss| 6e-5 ... 4e-4, features 4.6e-3 ... 6.2e-3):
+# the north-star's own 1e-3 on the loss, 8e-3 on the unit-norm features
+CFG4_BOUNDS = {"bf16": (1e-3, 5e-3), "fp8": (1e-3, 8e-3)}
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp8"])

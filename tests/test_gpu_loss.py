@@ -138,12 +138,14 @@ def test_spatial_loss_large_vs_oracle():
 
 
 @pytest.mark.parametrize("which", ["clip", "spatial"])
-def test_head_at_8gpu_per_rank_size_vs_oracle(which):
-    """BASELINE configs[2]/[3] per-rank head workload emulated on one GPU: local batch 256 of a global batch 2048,
-    D = 512, rank 3 of 8, features read in place from a padded gather buffer -- loss, every gradient and the time."""
+@pytest.mark.parametrize("B,D,ms_bound", [(256, 512, 0.6), (1024, 768, 2.5)])
+def test_head_at_8gpu_per_rank_size_vs_oracle(which, B, D, ms_bound):
+    """Per-rank head workload of an 8-GPU run emulated on one GPU, rank 3 of 8, features read in place from a padded gather
+    buffer -- loss, every gradient and the time.  (256, 512): BASELINE configs[2]/[3], local batch 256 of a global batch
+    2048.  (1024, 768): configs[4], local batch 1024 of a global batch 8192, ViT-L/14's embed_dim (round 4)."""
     C = _head()
     g = torch.Generator().manual_seed(3)
-    B, W, D, K, r = 256, 8, 512, 8, 3
+    W, K, r = 8, 8, 3
     G = B * W
     img = torch.nn.functional.normalize(torch.randn(G, D, generator=g), dim=-1)
     txt = torch.nn.functional.normalize(img + 0.7 * torch.randn(G, D, generator=g), dim=-1)
@@ -187,4 +189,4 @@ def test_head_at_8gpu_per_rank_size_vs_oracle(which):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     print(f"[head {which}] B={B} G={G} D={D}: {ms:.3f} ms per forward+backward")
-    assert ms < 0.6, ms          # wall incl. Python launch overhead of ~14 launches; kernel time is reported by tools/bench_head.py
+    assert ms < ms_bound, ms     # wall incl. Python launch overhead of ~14 launches; kernel time is reported by tools/bench_head.py
