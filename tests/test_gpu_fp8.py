@@ -297,3 +297,87 @@ def test_delayed_scaling_outputs_of_the_gelu_epilogues():
     assert float((out.double() - exact).abs().max() / exact.abs().max()) < 1e-3
     full = hf.double() @ w.cuda().double().t()
     assert float((out.double() - full).norm() / full.norm()) < 0.05
+
+
+def test_fp8_delayed_scaling_state_is_history_checkpointed_and_not_touched_by_eval(tmp_path):
+    """Round 4 (advisor, round 3): the delayed-scaling state (a) follows the maximum of the last FP8_AMAX_HISTORY steps, (b) is
+    neither consumed nor updated by a forward under torch.no_grad() -- an evaluation gives the same numbers whether or not
+    training steps ran before it in the same process --, (c) is reset when the weights are replaced and (d) travels in the
+    trainer's checkpoint, so that a resumed run continues bit for bit."""
+    import functools
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data, losses, model_configs as mc, module, net, ops, optim
+    from spatial_clip_amd.trainer import Trainer
+    # (a) the history kernel
+    n = 3
+    amax = torch.zeros((n, 64), device="cuda"); hist = torch.zeros((4, n), device="cuda")
+    scale, inv = torch.zeros(n, device="cuda"), torch.ones(n, device="cuda")
+    for step, peak in enumerate([(4.0, 1.0, 0.0), (1.0, 100.0, 0.0), (1.0, 1.0, 0.0), (1.0, 1.0, 0.0), (1.0, 1.0, 0.0)]):
+        amax[:, 5] = torch.tensor(peak, device="cuda")
+        ops.fp8_scale_update(amax, scale, inv, margin_bits=1, hist=hist, slot=step % 4)
+        assert float(amax.abs().max()) == 0.0
+        if step == 3:       # four steps back the first tensor peaked at 4, the second at 100 one step later: still remembered
+            assert scale.tolist()[:2] == [2.0 ** (6 - 1), 2.0 ** (2 - 1)] and float(scale[2]) == 0.0
+    assert scale.tolist()[:2] == [2.0 ** (8 - 1), 2.0 ** (2 - 1)]      # step 4 overwrote the slot of step 0 (peak 4 -> 1)
+    torch.testing.assert_close(inv[:2], 1.0 / scale[:2])
+
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 128, 3, 64), text=None, gene=mc.GeneCfg(512, 0, "transformer", 64, 128, 2, 64))
+
+    def make(seed=9):
+        nn_ = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=seed, precision="fp8")
+        mm = module.SpatialClipLitModule(
+            nn_, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True),
+            functools.partial(optim.FusedAdamW, lr=2e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+            functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+
+        class T:
+            max_steps, max_epochs, estimated_stepping_batches = 20, None, 20
+        mm.trainer = T()
+        oc = mm.configure_optimizers()
+        return nn_, mm, oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+
+    db = {k: v.cuda() for k, v in data.synthetic_batch(32, 32, 512, K=4, step=0).items()}
+
+    def steps(mm, opt, sched, k, first=0):
+        out = []
+        for s in range(first, first + k):
+            loss = mm.training_step(db, s)
+            loss.backward()
+            opt.step(grad_scale=1.0, max_norm=1.0)
+            sched.step()
+            out.append(float(loss.detach()))
+        return out
+
+    # (b) evaluation before and after training steps at lr = 0 (same weights): identical, and it leaves the state alone
+    n1, m1, opt1, sch1 = make()
+    with torch.no_grad():
+        f0 = n1(db["images"], db["texts"])["image_features"].clone()
+    st = n1.vision.stack
+    assert not st._dq_ready and float(st._dq_amax.abs().max()) == 0.0
+    for g in opt1.param_groups:
+        g["lr"] = g["initial_lr"] = 0.0
+    steps(m1, opt1, sch1, 2)
+    assert st._dq_ready and float(st._dq_scale.max()) > 0.0
+    snap = (st._dq_scale.clone(), st._dq_hist.clone(), st._dq_step)
+    with torch.no_grad():
+        f1 = n1(db["images"], db["texts"])["image_features"]
+    assert torch.equal(f0, f1)
+    assert torch.equal(snap[0], st._dq_scale) and torch.equal(snap[1], st._dq_hist) and snap[2] == st._dq_step
+    assert float(st._dq_amax.abs().max()) == 0.0
+    # (c) replacing the weights forgets the history
+    n1.load_state_dict(n1.state_dict())
+    assert not st._dq_ready and float(st._dq_scale.max()) == 0.0 and float(st._dq_hist.max()) == 0.0
+
+    # (d) checkpoint round trip: 5 steps in one go == 3 steps, save, load into a fresh model, 2 more steps
+    n2, m2, opt2, sch2 = make()
+    ref = steps(m2, opt2, sch2, 5)
+    n3, m3, opt3, sch3 = make()
+    a = steps(m3, opt3, sch3, 3)
+    path = str(tmp_path / "fp8.ckpt")
+    Trainer.save_checkpoint(path, m3, opt3, sch3, 3)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck["fp8_scaling"]) == {"vision", "second"} and ck["fp8_scaling"]["vision"]["ready"]
+    n4, m4, opt4, sch4 = make(seed=1)                      # different initial weights: everything must come from the file
+    assert Trainer.load_checkpoint(path, m4, opt4, sch4) == 3
+    b = steps(m4, opt4, sch4, 2, first=3)
+    assert a + b == ref, (a, b, ref)
