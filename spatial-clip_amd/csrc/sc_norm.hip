@@ -107,73 +107,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-// Two rows per wave for bf16 input rows (round 4).  A bf16 row of 768 values is 1.5 KB: with one row per wave a CU has at most
-// 32 x 1.5 KB in flight, and the kernel ran at 4.5 TB/s (34.6 us per 155 MB launch) -- bound by memory round trips, not by
-// HBM.  Both rows' loads are issued before the first reduction; arithmetic and results are those of ln_fwd_kernel, bit for bit.
-template <int NV>
-__global__ __launch_bounds__(256) void ln_fwd2_kernel(const bf16* __restrict__ x, long long ldx, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, bf16* __restrict__ y, long long ldy,
-                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int d,
-                                                      float eps) {
-    const int lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int row0 = rows - 1 - 2 * pair;              // last rows first: see ln_fwd_kernel
-    if (row0 < 0) return;
-    const int row1 = row0 - 1;                         // may be -1 (odd row count): clamped for the loads, never stored
-    const int nv = d >> 2;
-    f32x4 v[2][NV];
-    float s[2] = {0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const bf16* xr = x + (long long)max(r ? row1 : row0, 0) * ldx;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = i * 64 + lane;
-            if (e < nv) v[r][i] = ldbf4(xr + e * 4);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (i * 64 + lane < nv) s[r] += v[r][i][0] + v[r][i][1] + v[r][i][2] + v[r][i][3];
-    float mu[2], rs[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) mu[r] = sc_wave_sum(s[r]) / (float)d;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (i * 64 + lane < nv) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { const float t = v[r][i][c] - mu[r]; q += t * t; }
-            }
-        rs[r] = rsqrtf(sc_wave_sum(q) / (float)d + eps);
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int row = r ? row1 : row0;
-        if (row < 0) continue;
-        if (lane == 0) {
-            if (mean) mean[row] = mu[r];
-            if (rstd) rstd[row] = rs[r];
-        }
-        bf16* yr = y + (long long)row * ldy;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = i * 64 + lane;
-            if (e < nv) {
-                const f32x4 g = ld4(gamma + e * 4), b = ld4(beta + e * 4);
-                f32x4 o;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = (v[r][i][c] - mu[r]) * rs[r] * g[c] + b[c];
-                stbf4(yr + e * 4, o);
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------ LayerNorm backward
 // dres_new = (accumulate ? dres : 0) + LNbwd(dy) (accumulate = -P: dres only holds rows r % P == 0); also emits the bf16 copy of dres_new (the A operand of
 // the next dgrad / wgrad GEMMs) and per-block partials of dgamma, dbeta and colsum(dres_new).
@@ -571,15 +504,11 @@ static int ln_fwd_launch(const float* x, long long ldx, const float* gamma, cons
     SC_CHECK(y8 == nullptr || (scale_inv != nullptr && (ldy8 % 4) == 0 && ldy8 >= d),
              "sc_layernorm_fwd_q8: fp8 output needs scale_inv and a row stride that is a multiple of 4 (ldy8=%lld)", ldy8);
     const int nvv = (d / 4 + 63) / 64;
-    static const bool one_row = getenv("SC_LN_FWD2") && getenv("SC_LN_FWD2")[0] == '0';      // A/B switch
 #define SC_LN_FWD(NV)                                                                                                     \
     do {                                                                                                                  \
         if (xb) {                                                                                                         \
             if (y8) ln_fwd_kernel<NV, true, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                       \
                 x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, (unsigned char*)y8, ldy8, scale_inv);       \
-            else if (rows >= 4096 && NV <= 4 && !one_row)                                                                 \
-                ln_fwd2_kernel<NV><<<(rows + 7) / 8, 256, 0, (hipStream_t)stream>>>(                                      \
-                    (const bf16*)x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps);                           \
             else ln_fwd_kernel<NV, false, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                         \
                 x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, nullptr, 0, nullptr);                       \
         } else if (y8) ln_fwd_kernel<NV, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                          \
