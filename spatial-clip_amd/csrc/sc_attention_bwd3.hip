@@ -205,8 +205,9 @@ __global__ __launch_bounds__(512) void attn_bwd3_kernel(const bf16* __restrict__
         const float* sdel = slse + Lp;
         const unsigned u1 = (unsigned)(i + 1);
 
-        // dQ of query block bq (this wave is its reducer): one MFMA chain per output fragment over the NW key tiles
-        auto reduce = [&](int bq) {
+        // dQ of the query rows [32 bq + 16 a0, 32 bq + 16 a1) (this wave is their reducer): one MFMA chain per output fragment
+        // over the NW key tiles
+        auto reduce = [&](int bq, int a0, int a1) {
             lds_wait_ge(ctr0 + 4 * bq, (unsigned)NW * u1);                // every key wave has left its dS tile of block bq
             const char* slot = ring + (bq % RING) * SLOT;
             f32x4 dq[2][DT];
@@ -218,20 +219,28 @@ __global__ __launch_bounds__(512) void attn_bwd3_kernel(const bf16* __restrict__
             for (int kw = 0; kw < NW; ++kw) {          // not unrolled: 24 fragment registers per key tile, not 24 NW
                 bf16x8 dst[2], ktr[DT];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) dst[a] = frag_tr_ds(slot + kw * 2048, a * 16, li, lg);
+                for (int a = 0; a < 2; ++a)
+                    if (a >= a0 && a < a1) dst[a] = frag_tr_ds(slot + kw * 2048, a * 16, li, lg);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) ktr[dt] = frag_tr<DH>(Kimg, kw * 32, dt * 16, li, lg);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
+                    if (a >= a0 && a < a1) {
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) dq[a][dt] = sc_mfma16(ktr[dt], dst[a], dq[a][dt]);
+                        for (int dt = 0; dt < DT; ++dt) dq[a][dt] = sc_mfma16(ktr[dt], dst[a], dq[a][dt]);
+                    }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // all tiles of the slot are consumed by this wave alone until done[bq] moves: its own tile is the staging area
-            char* tile = ring + (bq % RING) * SLOT + wave * 2048;
+            // staging area.  A whole-block reducer is the only reader of the slot until done[bq] moves: its own tile there.  The two
+            // half-block reducers of the last block read EACH OTHER's tiles, so they stage in the slot a block NB would take
+            // (free once block NB - RING is reduced; the same tile serves this wave's dK / dV stores afterwards)
+            const bool whole = (a1 - a0 == 2);
+            if (!whole && NB >= RING) lds_wait_ge(ctr0 + 4 * NB + 4 * (NB - RING), u1);
+            char* tile = ring + ((whole ? bq : NB) % RING) * SLOT + wave * 2048;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) store_rows16(tile, dq[a], scale, bq * 32 + a * 16, (long long)h * DH, b);
-            if (lane == 0) lds_bump(ctr0 + 4 * NB + 4 * bq);             // done[bq] = i + 1
+            for (int a = 0; a < 2; ++a)
+                if (a >= a0 && a < a1) store_rows16(tile, dq[a], scale, bq * 32 + a * 16, (long long)h * DH, b);
+            if (lane == 0 && a1 - a0 == 2) lds_bump(ctr0 + 4 * NB + 4 * bq);     // done[bq] = i + 1 (only whole-block reducers are waited for)
         };
 
         // ---------------- this wave's K row fragments (B operand of S) stay in registers for the head
@@ -321,9 +330,14 @@ __global__ __launch_bounds__(512) void attn_bwd3_kernel(const bf16* __restrict__
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // rows of block j read, dS tile written
             if (lane == 0) lds_bump(ctr0 + 4 * j);                        // ready[j]
-            // this wave reduces block `wave` one step behind (the other key waves are through it by then; the last wave
-            // has no later step and reduces right after its last one)
-            if (j == wave + 1 || (j == NB - 1 && wave == NB - 1)) reduce(wave);
+            // this wave reduces block `wave` one step behind (the other key waves are through it by then).  The last block has
+            // no later step: its reduction is the serial tail of the head, so two waves share it (16 query rows each)
+            if (j == wave + 1) reduce(wave, 0, 2);
+            if (j == NB - 1) {
+                if (NB == 1) reduce(0, 0, 2);
+                else if (wave == NB - 1) reduce(NB - 1, 0, 1);
+                else if (wave == 0) reduce(NB - 1, 1, 2);
+            }
         }
         // ---------------- next head's V fragments first, then this head's dK / dV stores (they drain under the loads)
         const int next = head + gridDim.x;
