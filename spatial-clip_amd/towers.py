@@ -48,13 +48,26 @@ def _splitk_for_group(shapes, k: int, one_round: bool = False) -> int:
     return best
 
 
+MAX_SIDE_KTILES = 200       # longest K chain (64-token tiles) a grouped weight-gradient workgroup may own
+
+
 def _wgrad_group_mode() -> str:
-    """Read at every backward: SC_WGRAD_GROUP = 3 (default: the two weight gradients of each branch of a block in one
-    launch of at most ONE round of workgroups), 2 (the same with whole rounds filled: the MLP pair becomes two rounds),
-    1 (attention branch grouped only), 4 (all four of a block in one launch), 0 (one launch per Linear, rounds 1-3).
-    Same-box A/B, profiles/r04_wgrad_group_ab.txt: -0.06 ... -0.16 ms per step for 1 and 3, +0.2 ... +0.4 ms for the
-    multi-round launches of 2 and 4 on one box (they hold the data-gradient chain back)."""
-    return os.environ.get("SC_WGRAD_GROUP", "3")
+    """Read at every backward: SC_WGRAD_GROUP = auto (default), 0 (one launch per Linear, rounds 1-3), 1 (attention branch
+    grouped), 2 / 3 (both branches grouped, whole rounds / one round), 4 (all four of a block in one launch) -- A/B switch.
+    ``auto`` groups a branch's two weight gradients when the grouped launch fits ONE round of workgroups with K chains of at
+    most MAX_SIDE_KTILES tiles: the weight gradients run beside the data-gradient chain, and long-lived or multi-round side
+    launches hold the chain's kernels back.  Same-box A/B (profiles/r04_wgrad_group_ab.txt): ViT-B/16 -0.06 ... -0.16 ms per
+    step with the attention branch grouped (113-tile chains); the MLP pair at one round (263-tile chains) -0.04 more on one
+    box; ViT-L/14 (257- / 514-tile chains) +2.4 ms bf16, +3.9 ms e4m3 with both grouped, +1.3 ms e4m3 with the attention
+    branch alone -- hence the cap."""
+    return os.environ.get("SC_WGRAD_GROUP", "auto")
+
+
+def _group_ok(mode: str, branch: str, shapes, k: int) -> bool:
+    if mode == "auto":
+        s = _splitk_for_group(shapes, k, one_round=True)
+        return ((k + 63) // 64 + s - 1) // s <= MAX_SIDE_KTILES
+    return mode in ("2", "3") or (mode == "1" and branch == "attn")
 
 
 class _Bufs:
@@ -444,8 +457,8 @@ class TransformerStack:
             mlp_probs = [(g0, h, g("mlp.c_proj.weight"), None, d, mlp), (dU, a2, g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), mlp, d)]
 
             def w_mlp(g0=g0, h=h, dU=dU, a2=a2, g=g, probs=mlp_probs):
-                if wg_mode in ("2", "3"):      # both weight gradients of the MLP branch in one launch + one slab reduction
-                    ops.gemm_wgrad_group(probs, K=M, splitk=_splitk_for_group([(d, mlp), (mlp, d)], M, one_round=wg_mode == "3"))
+                if _group_ok(wg_mode, "mlp", [(d, mlp), (mlp, d)], M):      # both weight gradients of the MLP branch in one launch
+                    ops.gemm_wgrad_group(probs, K=M, splitk=_splitk_for_group([(d, mlp), (mlp, d)], M, one_round=wg_mode != "2"))
                     return
                 ops.gemm(ops.TN, ops.EPI_F32, g0, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M, splitk=_splitk_for(d, mlp, M))
                 ops.gemm_wgrad_bias(dU, a2, g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), M=mlp, N=d, K=M,
@@ -482,8 +495,8 @@ class TransformerStack:
                 if wg_mode == "4":      # all four weight gradients of the block in one launch
                     ops.gemm_wgrad_group(more + probs, K=M, splitk=_splitk_for_group([(d, mlp), (mlp, d), (d, d), (3 * d, d)], M))
                     return
-                if wg_mode in ("1", "2", "3"):      # out_proj (9 tiles) no longer needs split-K 28 to fill the chip
-                    ops.gemm_wgrad_group(probs, K=M, splitk=_splitk_for_group([(d, d), (3 * d, d)], M))
+                if _group_ok(wg_mode, "attn", [(d, d), (3 * d, d)], M):      # out_proj (9 tiles) no longer needs split-K 28 to fill the chip
+                    ops.gemm_wgrad_group(probs, K=M, splitk=_splitk_for_group([(d, d), (3 * d, d)], M, one_round=wg_mode != "2"))
                     return
                 ops.gemm(ops.TN, ops.EPI_F32, g1, o, g("attn.out_proj.weight"), M=d, N=d, K=M, splitk=_splitk_for(d, d, M))
                 ops.gemm_wgrad_bias(dqkv, a1, g("attn.in_proj_weight"), g("attn.in_proj_bias"), M=3 * d, N=d, K=M,
