@@ -161,7 +161,7 @@ def loss_delta_vs_oracle(m, n, cfg, batch_cpu, loss_kind: str, dtype: str = "bf1
 
 def pmc_traffic_nt():
     """HBM bytes per NT-GEMM launch from the committed rocprofv3 PMC passes (profiles/README.md); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_summary.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic_summary.json")
     try:
         d = json.load(open(path))
     except Exception:
