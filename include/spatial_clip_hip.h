@@ -102,6 +102,14 @@ int sc_fp8_scale_update(float* amax_slots, float* scale, float* scale_inv, int n
  * saturating clamp. */
 int sc_fp8_scale_update_hist(float* amax_slots, float* hist, int hist_len, int slot, float* scale, float* scale_inv, int n,
                              int margin_bits, void* stream);
+/* e4m3 weight (+ bias) gradient (round 4): dW[M,N](f32, dense) = dy_scale_inv * x_scale_inv * dY8[K,M]^T . X8[K,N], both operands
+ * token-major e4m3 bytes quantised with ONE scale per tensor -- the reduction runs over the tokens, so the per-token-row scales of
+ * sc_layernorm_*_q8 cannot be used here; the delayed per-tensor copies of sc_gemm_fp8_q / sc_layernorm_*_t8 can.  dbias[M] (may be
+ * NULL) = dy_scale_inv * column sums of dY8.  M >= 256, N >= 192, M % 16 == N % 16 == 0, K % 128 == 0; lddy / ldx in bytes (% 16);
+ * ws: sc_gemm_wgrad_ws_floats(M, N, K, splitk) floats. */
+int sc_gemm_wgrad_fp8(const void* dY8, long long lddy, const float* dy_scale_inv, const void* X8, long long ldx,
+                      const float* x_scale_inv, int M, int N, int K, float* dW, int ldw, float* dbias, int splitk, float* ws,
+                      void* stream);
 /* The quantiser fused into the kernels that hold a complete row (round 3): LayerNorm forward also emits the e4m3 copy
  * of its output (A operand of the qkv / c_fc forward GEMMs), LayerNorm backward the e4m3 copy of the new residual
  * gradient (A operand of the c_proj / out_proj data-gradient GEMMs; SC_EPI_BF16_DGELU takes aux = the pre-GELU tensor),

@@ -384,6 +384,40 @@ extern "C" int sc_gemm_wgrad_bias(const void* dY, int lddy, const void* X, int l
 }
 
 
+// ---- e4m3 weight (+ bias) gradient: dW[M,N] = s_dy s_x sum_k dY8[k,m] X8[k,n], per-tensor scales (include/spatial_clip_hip.h) ----
+extern "C" int sc_gemm_wgrad_fp8(const void* dY8, long long lddy, const float* dy_scale_inv, const void* X8, long long ldx,
+                                 const float* x_scale_inv, int M, int N, int K, float* dW, int ldw, float* dbias, int splitk,
+                                 float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SC_CHECK(M > 0 && N > 0 && K > 0 && dY8 && X8 && dW && ws && dy_scale_inv && x_scale_inv, "sc_gemm_wgrad_fp8: null / empty argument");
+    SC_CHECK((lddy % 16) == 0 && (ldx % 16) == 0 && ((uintptr_t)dY8 % 16) == 0 && ((uintptr_t)X8 % 16) == 0 && ((uintptr_t)dW % 16) == 0,
+             "sc_gemm_wgrad_fp8: operand rows must be 16-byte aligned (lddy=%lld ldx=%lld)", lddy, ldx);
+    SC_CHECK(ldw == N, "sc_gemm_wgrad_fp8: dW must be dense (ldw == N)");
+    if (splitk < 1) splitk = 1;
+    const long long slab_floats = sc_gemm_slab_floats(M, N, K, splitk);
+    float* slabs = ws;
+    float* cs_part = ws + ((slab_floats + 15) / 16) * 16;
+    GemmArgs g;
+    g.A = (const bf16*)dY8; g.B = (const bf16*)X8; g.M = M; g.N = N; g.K = K; g.lda = (int)lddy; g.ldb = (int)ldx;
+    g.C = dW; g.ldc = ldw; g.C2 = nullptr; g.ldc2 = 0; g.bias = nullptr; g.res = nullptr; g.ldres = 0;
+    g.aux = nullptr; g.ldaux = 0; g.tile_offset = 0;
+    g.colsum = dbias ? cs_part : nullptr;
+    g.a_scale = dy_scale_inv; g.b_scale = x_scale_inv;
+    const int took = sc_gemm8p_tn_fp8(g, splitk, slab_floats ? slabs : nullptr, st);
+    if (took < 0) return took;
+    SC_CHECK(took == 1, "sc_gemm_wgrad_fp8: shape outside the kernel's range (M=%d N=%d K=%d: M >= 256, N >= 192, M %% 16 == N %% 16 == 0, K %% 128 == 0)", M, N, K);
+    if (g.splitk > 1 || dbias != nullptr) {
+        const long long n4 = (long long)M * N / 4;
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < (M + 255) / 256) blocks = (M + 255) / 256;
+        reduce_slabs_kernel<<<blocks, 256, 0, st>>>(dW, g.splitk > 1 ? slabs : nullptr, g.splitk, g.slab_stride, n4, dbias, cs_part,
+                                                    dbias ? M : 0);
+        SC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 // ---- several weight (+ bias) gradients over one token axis in one launch (include/spatial_clip_hip.h) ----
 static long long wgrad_group_layout(const sc_wgrad_desc* d, int n, int K, int splitk, long long* slab_off, long long* cs_off) {
     // workspace = per problem [splitk slabs of M x N | splitk partial column sums of M], 16-float aligned; the plain

@@ -775,6 +775,249 @@ int launch_tn(const GemmArgs& g, int nblocks, hipStream_t st) {
 }
 
 // =====================================================================================================================
+// FP8 (OCP e4m3) TN variant (round 4): weight gradients dW[m, n] = sum_k A8[k, m] B8[k, n] with both operands token-major bytes
+// quantised with ONE scale per tensor (the reduction runs over the tokens, so a per-token scale cannot be pulled out of it).
+//   K tile = 128 tokens; half-tile image = [128 k][128 columns] bytes (16 KiB, 128-B rows): the ring, the DMA piece count and the
+//   phase schedule are byte-for-byte those of the bf16 TN kernel above, with twice the k per tile.
+//   Fragments: the MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) wants, in lane (g = lane >> 4, r = lane & 15), the 32 consecutive k
+//   [32 g, 32 g + 32) of output row r, one per byte.  ds_read_b64_tr_b8 (layout probed with tools/micro/tr_b8_layout.hip: lane
+//   2 q + p of a 16-lane group supplies the address of (row q, byte columns 8 p .. 8 p + 7); lane i receives column i of rows
+//   0 .. 7) delivers 8 of them: four reads per fragment at k offsets 0, 8, 16, 24 (+1024 B each in the image).
+//   Swizzle: 16-byte chunk ^= ((k >> 1) & 3) | ((k >> 5) & 1) << 2 -- the four same-parity rows of an 8-row block and the two
+//   row blocks a 32-lane half reads land on eight different 16-byte bank windows; the per-lane swizzle term does not depend on
+//   which of the four reads it is, so they are immediate offsets off one address.
+//   C = a_scale_inv * b_scale_inv * sum (fp32 slabs as above); the fused bias gradient sums the e4m3 A fragments (x a_scale_inv).
+typedef __attribute__((ext_vector_type(8))) int i32x8t;
+struct FragT8 {
+    union {
+        i32x8t v;               // the MFMA operand: 8 consecutive registers
+        u32x2 q[4];             // k blocks 0..7, 8..15, 16..23, 24..31 of this lane's group (one transposed read each)
+    };
+};
+template <int OFF>
+SC_DEVICE u32x2 tr8_asm(unsigned lds_addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF) : "memory");
+    return r;
+}
+// Q = half-tile index inside one ring parity: its byte offset (<= 48 KiB) rides in the instruction's 16-bit offset field, so a
+// fragment needs ONE address register per ring parity instead of one per ring slot (with the slot folded into the address the
+// compiler keeps ~24 hoisted address registers and spills)
+template <int Q>
+SC_DEVICE void t8_read(unsigned addr, FragT8& f) {
+    f.q[0] = tr8_asm<Q * HALF>(addr);
+    f.q[1] = tr8_asm<Q * HALF + 1024>(addr);
+    f.q[2] = tr8_asm<Q * HALF + 2048>(addr);
+    f.q[3] = tr8_asm<Q * HALF + 3072>(addr);
+}
+SC_DEVICE void t8_wait2(FragT8 (&f)[2]) {          // retire every register the asm reads above wrote (see tn_wait4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].v), "+v"(f[1].v) :: "memory");
+}
+SC_DEVICE void t8_wait4(FragT8 (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].v), "+v"(f[1].v), "+v"(f[2].v), "+v"(f[3].v) :: "memory");
+}
+SC_DEVICE i32x8t t8_cat(const FragT8& f) { return f.v; }
+SC_DEVICE float t8_sum(const FragT8& f) {          // sum of this lane's 32 e4m3 values
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int v = (int)f.q[j][w];
+            s += __builtin_amdgcn_cvt_f32_fp8(v, 0) + __builtin_amdgcn_cvt_f32_fp8(v, 1) + __builtin_amdgcn_cvt_f32_fp8(v, 2) +
+                 __builtin_amdgcn_cvt_f32_fp8(v, 3);
+        }
+    return s;
+}
+
+struct StagerT8 {
+    // wave-uniform base (SGPRs) + 32-bit per-lane offset: the DMA takes the scalar-base addressing form and the eight source
+    // addresses cost 8 VGPRs instead of 16 (with 64-bit pointers the kernel spilled them and reloaded one before every DMA)
+    const unsigned char* base[4];
+    unsigned off[4];            // piece 0 of each half-tile kind; piece 1 is 64 k rows further: a scalar addend (step / 2)
+    long long step[4];          // bytes per K tile (128 source rows) for each half-tile kind
+    int nt;
+    int wave;
+};
+
+template <int D, int PH>
+SC_DEVICE void phase_t8(char* smem, unsigned lds0, const StagerT8& S, int t, const unsigned (&a_off)[4], const unsigned (&b_off)[2],
+                        FragT8 (&a)[4], FragT8 (&b0)[2], FragT8 (&b1)[2], f32x4 (&acc)[8][4], bool do_cs, int wc, float (&cs)[2]) {
+    constexpr unsigned pd = D * 4 * HALF;               // ring parity base, part of the (hoisted) address
+    if (PH == 1) { t8_read<1>(lds0 + pd + b_off[0], b0[0]); t8_read<1>(lds0 + pd + b_off[1], b0[1]); }
+    if (PH == 2) { t8_read<2>(lds0 + pd + b_off[0], b1[0]); t8_read<2>(lds0 + pd + b_off[1], b1[1]); }
+    if (PH == 1) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) t8_read<0>(lds0 + pd + a_off[ii], a[ii]);
+    }
+    if (PH == 3) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) t8_read<3>(lds0 + pd + a_off[ii], a[ii]);
+    }
+    constexpr int q = (PH + 1) & 3;
+    constexpr int DS = PH <= 2 ? (D ^ 1) : D;
+    const int ts = t + (PH <= 2 ? 1 : 2);
+    if (ts < S.nt) {
+        const unsigned char* kb = S.base[q] + ts * S.step[q];
+        unsigned o0 = S.off[q];
+        asm volatile("" : "+v"(o0));                      // keep (scalar base + 32-bit offset): a hoisted 64-bit sum costs 2 VGPRs each
+        dma16(kb + o0, smem + slot(DS, q) + S.wave * 1024);
+        dma16(kb + (S.step[q] >> 1) + o0, smem + slot(DS, q) + (8 + S.wave) * 1024);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (PH == 1) { t8_wait2(b0); t8_wait4(a); }
+    if (PH == 2) t8_wait2(b1);
+    if (PH == 3) t8_wait4(a);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int mi = PH >= 3 ? 1 : 0;
+    constexpr int nj = (PH == 2 || PH == 3) ? 1 : 0;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const i32x8t af = t8_cat(a[ii]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            acc[mi * 4 + ii][nj * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                t8_cat(nj ? b1[jj] : b0[jj]), af, acc[mi * 4 + ii][nj * 2 + jj], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        if ((PH == 1 || PH == 3) && do_cs && ii == wc) cs[mi] += t8_sum(a[ii]);     // fused bias gradient, as in the bf16 kernel
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int D>
+SC_DEVICE void ktile_t8(char* smem, unsigned lds0, const StagerT8& S, int t, const unsigned (&a_off)[4], const unsigned (&b_off)[2],
+                        FragT8 (&a)[4], FragT8 (&b0)[2], FragT8 (&b1)[2], f32x4 (&acc)[8][4], bool do_cs, int wc, float (&cs)[2]) {
+    phase_t8<D, 1>(smem, lds0, S, t, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+    phase_t8<D, 2>(smem, lds0, S, t, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+    phase_t8<D, 3>(smem, lds0, S, t, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+    phase_t8<D, 4>(smem, lds0, S, t, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+}
+
+// g.A / g.B: e4m3 bytes [K tokens][M] / [K][N], lda / ldb in BYTES; g.K tokens (k_per_split a multiple of 128);
+// g.a_scale / g.b_scale: ONE dequantisation factor each (device scalars)
+__global__ __launch_bounds__(512, 2) void gemm8p_tn_f8_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK8 = 128;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int li = lane & 15, lg = lane >> 4;
+
+    int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = idx % g.ntn;
+    idx /= g.ntn;
+    const int tm = idx % g.ntm;
+    const int z = idx / g.ntm;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const unsigned char* A8 = reinterpret_cast<const unsigned char*>(g.A);
+    const unsigned char* B8 = reinterpret_cast<const unsigned char*>(g.B);
+
+    StagerT8 S;
+    S.nt = (kend - kbeg) / BK8;
+    S.wave = wave;
+    S.step[0] = S.step[3] = (long long)BK8 * g.lda;
+    S.step[1] = S.step[2] = (long long)BK8 * g.ldb;
+    {
+        // piece p of a half-tile = k rows [8 (8 p + wave), + 8): rows kr and kr + 64 have the same swizzle term (bits 1, 2, 5 of k)
+        const int kr = wave * 8 + (lane >> 3);                           // k row of the half-tile image, 128 B per row
+        const int sw = ((kr >> 1) & 3) | (((kr >> 5) & 1) << 2);
+        const int c = ((lane & 7) ^ sw) << 4;                            // logical byte column held at physical chunk lane & 7
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ca = min(m0 + h * 128 + c, g.M - 16), cb = min(n0 + h * 128 + c, g.N - 16);
+            S.off[h ? 3 : 0] = (unsigned)kr * (unsigned)g.lda + (unsigned)ca;
+            S.off[h ? 2 : 1] = (unsigned)kr * (unsigned)g.ldb + (unsigned)cb;
+        }
+    }
+    S.base[0] = S.base[3] = A8 + (size_t)kbeg * g.lda;
+    S.base[1] = S.base[2] = B8 + (size_t)kbeg * g.ldb;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+    unsigned a_off[4], b_off[2];
+    {
+        const int sw = ((li >> 2) & 3) | ((lg & 1) << 2);                // swizzle term of rows 32 lg + 8 j + (li >> 1), any j
+        const int row = (32 * lg + (li >> 1)) * 128 + (li & 1) * 8;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) a_off[ii] = row + (((wr * 4 + ii) ^ sw) << 4);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) b_off[jj] = row + (((wc * 2 + jj) ^ sw) << 4);
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = g.colsum != nullptr && tn == 0;
+    float cs[2] = {0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int ts = s >> 2, q = s & 3;
+        if (ts < S.nt) {
+            const unsigned char* kb = S.base[q] + ts * S.step[q];
+            dma16(kb + S.off[q], smem + slot(ts & 1, q) + wave * 1024);
+            dma16(kb + (S.step[q] >> 1) + S.off[q], smem + slot(ts & 1, q) + (8 + wave) * 1024);
+        }
+    }
+    if (S.nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    FragT8 a[4], b0[2], b1[2];
+    for (int kt = 0; kt < S.nt; kt += 2) {
+        ktile_t8<0>(smem, lds0, S, kt, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+        if (kt + 1 < S.nt) ktile_t8<1>(smem, lds0, S, kt + 1, a_off, b_off, a, b0, b1, acc, do_cs, wc, cs);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    const float sa = g.a_scale ? *g.a_scale : 1.0f, sb = g.b_scale ? *g.b_scale : 1.0f;
+    if (do_cs) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v = cs[h];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int m = m0 + h * 128 + wr * 64 + wc * 16 + li;
+            if (lg == 0 && m < g.M) g.colsum[(size_t)z * g.M + m] = v * sa;
+        }
+    }
+    const float sab = sa * sb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] *= sab;
+    float* ep = reinterpret_cast<float*>(smem) + wave * 64 * SC_EPI_LD;
+    EpiRegs<SC_EPI_F32> er;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc_epi_put(ep, i, j, li, lg, acc[h * 4 + i][j]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        sc_epilogue_store<SC_EPI_F32>(ep, er, m0 + h * 128 + wr * 64, n0 + wc * 32, lane, g, z, -1, 64, 128 - 32);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =====================================================================================================================
 // FP8 (OCP e4m3) NT variant: the same tile, ring, phase schedule and epilogues on one-byte operands.  A half-tile row
 // is still 128 bytes, i.e. 128 k values instead of 64, so the staging stream, swizzle and waits are byte-for-byte the
 // bf16 kernel's; the caller passes K / 2, lda / 2, ldb / 2 ("bf16 elements") and the MFMA section issues ONE
@@ -1030,6 +1273,38 @@ int sc_gemm8p_tn_group_launch(const GemmArgs* g, int n, hipStream_t st) {
         attr_done = true;
     }
     gemm8p_tn_group_kernel<<<total, 512, LDS_BYTES, st>>>(gg);
+    SC_LAUNCH_CHECK();
+    return 1;
+}
+
+// fp8 TN weight gradient: g.A / g.B e4m3 bytes [K][M] / [K][N] (lda / ldb in bytes), g.a_scale / g.b_scale device scalars, g.C fp32;
+// split-K through `slabs` exactly as the bf16 TN path.  1 = launched, 0 = shape outside the kernel's range.
+int sc_gemm8p_tn_fp8(GemmArgs& g, int splitk_req, float* slabs, hipStream_t st) {
+    if (g.M < 256 || g.N < 192 || (g.K % 128) != 0 || (g.M % 16) != 0 || (g.N % 16) != 0) return 0;
+    if ((g.lda % 16) != 0 || (g.ldb % 16) != 0) return 0;
+    g.ntm = (g.M + BM - 1) / BM;
+    g.ntn = (g.N + BN - 1) / BN;
+    const int ktiles = g.K / 128;
+    int splitk = splitk_req < 1 ? 1 : splitk_req;
+    if (slabs == nullptr) splitk = 1;
+    if (splitk > ktiles) splitk = ktiles;
+    const int tiles_per = (ktiles + splitk - 1) / splitk;
+    splitk = (ktiles + tiles_per - 1) / tiles_per;
+    g.splitk = splitk;
+    g.k_per_split = tiles_per * 128;
+    g.slab_stride = 0;
+    if (splitk > 1) {
+        if (g.ldc != g.N) return 0;
+        g.C = slabs;
+        g.slab_stride = (long long)g.M * g.N;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_tn_f8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES);
+        attr_done = true;
+    }
+    gemm8p_tn_f8_kernel<<<g.ntm * g.ntn * splitk, 512, LDS_BYTES, st>>>(g);
     SC_LAUNCH_CHECK();
     return 1;
 }

@@ -273,5 +273,7 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
 // grouped TN launch of the same kernel (several weight gradients over one token axis): plan the common split-K, then launch
 int sc_gemm8p_tn_group_plan(const GemmArgs* g, int n, int splitk_req, int* splitk_out, int* k_per_split);
 int sc_gemm8p_tn_group_launch(const GemmArgs* g, int n, hipStream_t st);
+// fp8 (e4m3) TN weight gradient (per-tensor scales; lda / ldb in bytes); 1 = launched, 0 = shape outside its range
+int sc_gemm8p_tn_fp8(GemmArgs& g, int splitk_req, float* slabs, hipStream_t st);
 // fp8 (e4m3) NT variant of the same kernel; g.K / lda / ldb in 2-byte units, g.a_scale / g.b_scale set
 int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st);

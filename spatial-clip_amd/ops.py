@@ -598,6 +598,31 @@ def fp8_scale_update(amax_slots: torch.Tensor, scale: torch.Tensor, scale_inv: t
                                          _stream()), "sc_fp8_scale_update")
 
 
+def gemm_wgrad_fp8(dy8: torch.Tensor, dy_scale_inv: torch.Tensor, x8: torch.Tensor, x_scale_inv: torch.Tensor, dw: torch.Tensor,
+                   dbias: Optional[torch.Tensor], *, M: int, N: int, K: int, splitk: int = 1) -> None:
+    """dW[M,N] = s_dy s_x dY8[K,M]^T . X8[K,N] (fp32) and dbias[M] = s_dy column sums of dY8: e4m3 operands with ONE scale per
+    tensor (``*_scale_inv``: one-element device tensors)."""
+    for t_, n in ((dy8, "dy8"), (x8, "x8")):
+        if not t_.is_cuda or t_.dtype != torch.uint8 or t_.stride(-1) != 1:
+            raise TypeError(f"gemm_wgrad_fp8: {n} must be a device uint8 (e4m3 bytes) matrix")
+    _req(dy_scale_inv, torch.float32, "dy_scale_inv"); _req(x_scale_inv, torch.float32, "x_scale_inv"); _req(dw, torch.float32, "dw")
+    if dbias is not None: _req(dbias, torch.float32, "dbias")
+    if not dw.is_contiguous() or dw.numel() != M * N:
+        raise ValueError("gemm_wgrad_fp8: dw must be a dense [M, N] tensor")
+    l = _lib.lib()
+    ws = workspace(l.sc_gemm_wgrad_ws_floats(M, N, K, splitk), dw.device, "wgrad")
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    rc = l.sc_gemm_wgrad_fp8(dy8.data_ptr(), dy8.stride(0), dy_scale_inv.data_ptr(), x8.data_ptr(), x8.stride(0),
+                             x_scale_inv.data_ptr(), M, N, K, dw.data_ptr(), N, _ptr(dbias), splitk, ws.data_ptr(), _stream())
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append(("gemm_tn_fp8", 2.0 * M * N * K, ev))
+    check(rc, "sc_gemm_wgrad_fp8")
+
+
 def gemm_fp8(epi: int, a8: torch.Tensor, a_scale_inv: torch.Tensor, b8: torch.Tensor, b_scale_inv: torch.Tensor,
              out: torch.Tensor, *, M: int, N: int, K: int, out2: Optional[torch.Tensor] = None,
              bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,

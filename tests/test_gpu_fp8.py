@@ -381,3 +381,28 @@ def test_fp8_delayed_scaling_state_is_history_checkpointed_and_not_touched_by_ev
     assert Trainer.load_checkpoint(path, m4, opt4, sch4) == 3
     b = steps(m4, opt4, sch4, 2, first=3)
     assert a + b == ref, (a, b, ref)
+
+
+def _e4m3(t):
+    return t.to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+@pytest.mark.parametrize("M,N,K,splitk,bias", [(256, 256, 128, 1, True), (512, 768, 128 * 5, 1, True), (768, 3072, 128 * 6, 3, False),
+                                               (3072, 768, 128 * 9, 4, True), (1024, 1024, 128 * 4, 2, True), (272, 208, 128 * 3, 1, True)])
+def test_wgrad_fp8_exact_on_representable_data(M, N, K, splitk, bias):
+    """sc_gemm_wgrad_fp8 (round 4): dW = s_dy s_x dY8^T . X8 with token-major e4m3 operands and per-tensor scales, fragments by
+    ds_read_b64_tr_b8.  Small integers are exact in e4m3 and every fp32 sum is exact: the kernel must equal the integer product
+    (and the fused bias gradient the column sums) bit for bit, over ring wrap (1 ... 9 K tiles), split-K and ragged tile edges."""
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    for rep in range(2):
+        dy = torch.randint(-4, 5, (K, M), generator=g).float()
+        x = torch.randint(-4, 5, (K, N), generator=g).float()
+        sy, sx = torch.tensor([0.5], device="cuda"), torch.tensor([4.0], device="cuda")
+        dw = torch.full((M, N), 9.0, device="cuda")
+        db = torch.full((M,), 9.0, device="cuda") if bias else None
+        ops.gemm_wgrad_fp8(_e4m3(dy).cuda(), sy, _e4m3(x).cuda(), sx, dw, db, M=M, N=N, K=K, splitk=splitk)
+        assert torch.equal(dw.cpu(), 2.0 * (dy.t() @ x)), (M, N, K, splitk, rep)
+        if bias:
+            assert torch.equal(db.cpu(), 0.5 * dy.sum(0)), (M, N, K, splitk, rep, "bias")
