@@ -178,6 +178,17 @@ int sc_layernorm_bwd(const void* dy, long long lddy, const float* x, long long l
                      const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
                      long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum, float* ws,
                      int rows, int d, void* stream);
+/* sc_layernorm_fwd_x16 / sc_layernorm_bwd_x16 with a SECOND e4m3 output quantised with one scale for the whole tensor (round 4):
+ * y_t8 = e4m3(value * *t_scale), max |value| of the launch max-reduced into t_amax[64] (delayed scaling, sc_fp8_scale_update*).
+ * These copies are the X / dY operands of sc_gemm_wgrad_fp8, whose reduction runs over the token rows. */
+int sc_layernorm_fwd_x16_t8(const void* x_bf16, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
+                            void* y_fp8, long long ldy8, float* scale_inv, void* y_t8, long long ldt8, const float* t_scale,
+                            float* t_amax, float* mean, float* rstd, int rows, int d, float eps, void* stream);
+int sc_layernorm_bwd_x16_t8(const void* dy, long long lddy, const void* x_bf16, long long ldx, const float* mean,
+                            const float* rstd, const float* gamma, const void* gin_bf16, long long ldgin, float* dres,
+                            long long lddres, int write_f32, void* gout_bf16, long long ldgout, void* gout_fp8, long long ldd8,
+                            float* scale_inv, void* gout_t8, long long ldt8, const float* t_scale, float* t_amax, int accumulate,
+                            float* dgamma, float* dbeta, float* colsum, float* ws, int rows, int d, void* stream);
 int sc_layernorm_bwd_reduce(const float* ws, int rows, int d, float* dgamma, float* dbeta, float* colsum,
                             void* stream);
 

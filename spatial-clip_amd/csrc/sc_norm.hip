@@ -34,6 +34,19 @@ SC_DEVICE float ln_row_scale(float amax_lane) {
     const float amax = sc_wave_max(amax_lane);
     return amax > 0.f ? exp2f(floorf(log2f(448.0f / amax))) : 1.0f;
 }
+// Second e4m3 copy with ONE scale for the whole tensor (round 4): the operand of the e4m3 WEIGHT-gradient GEMM, whose reduction
+// runs over the token rows -- a per-row scale cannot be pulled out of it.  Delayed scaling as for the GELU epilogues' copies
+// (sc_fp8.hip): quantise with the previous steps' scale *t_scale, max-reduce |value| of this launch into t_amax[64].
+struct LnT8 {
+    unsigned char* t8 = nullptr;
+    long long ldt8 = 0;
+    const float* t_scale = nullptr;
+    float* t_amax = nullptr;
+};
+SC_DEVICE void ln_t8_amax(float row_amax, float* slots, int row) {     // row_amax: wave-uniform, non-negative
+    unsigned* s = reinterpret_cast<unsigned*>(slots) + (row & 63);
+    if ((threadIdx.x & 63) == 0 && row_amax > __uint_as_float(*s)) atomicMax(s, __float_as_uint(row_amax));
+}
 
 // XB: the input rows are bf16 (the residual stream kept in bf16, SC_EPI_BF16_BIAS_RES); x then points at bf16 data
 template <int NV, bool Q8, bool XB = false>
@@ -42,7 +55,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      bf16* __restrict__ y, long long ldy, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int rows, int d, float eps,
                                                      unsigned char* __restrict__ y8, long long ldy8,
-                                                     float* __restrict__ scale_inv) {
+                                                     float* __restrict__ scale_inv, const LnT8 t8 = LnT8()) {
     const int lane = threadIdx.x & 63;
     // Rows are walked LAST ROW FIRST: the producer in front (a GEMM walking its tiles upwards) wrote the high rows last, so
     // they are the ones still in the 256-MB Infinity Cache; and the rows this kernel writes last are the low ones the next
@@ -104,6 +117,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             const int e = i * 64 + lane;
             if (e < nv) *reinterpret_cast<unsigned*>(y8r + e * 4) = ln_pack4_fp8(v[i], sc);
         }
+        if (t8.t8 != nullptr) {              // per-tensor copy for the weight-gradient GEMM
+            const float ts = *t8.t_scale;
+            unsigned char* tr = t8.t8 + (long long)row * t8.ldt8;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = i * 64 + lane;
+                if (e < nv) *reinterpret_cast<unsigned*>(tr + e * 4) = ln_pack4_fp8(v[i], ts);
+            }
+            ln_t8_amax(sc_wave_max(amax), t8.t_amax, row);
+        }
     }
 }
 
@@ -126,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      float* __restrict__ partial, int rows, int d, int accumulate,
                                                      unsigned char* __restrict__ d8, long long ldd8,
                                                      float* __restrict__ scale_inv, const bf16* __restrict__ gin = nullptr,
-                                                     long long ldgin = 0, int write_f32 = 1) {
+                                                     long long ldgin = 0, int write_f32 = 1, const LnT8 t8 = LnT8()) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -208,6 +231,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             for (int i = 0; i < NV; ++i) {
                 const int e = i * 64 + lane;
                 if (e < nv) *reinterpret_cast<unsigned*>(d8r + e * 4) = ln_pack4_fp8(g[i], sc);
+            }
+            if (t8.t8 != nullptr) {          // per-tensor copy of the new residual gradient: dY of the e4m3 c_proj weight gradient
+                const float ts = *t8.t_scale;
+                unsigned char* tr = t8.t8 + (long long)row * t8.ldt8;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int e = i * 64 + lane;
+                    if (e < nv) *reinterpret_cast<unsigned*>(tr + e * 4) = ln_pack4_fp8(g[i], ts);
+                }
+                ln_t8_amax(sc_wave_max(amax), t8.t_amax, row);
             }
         }
     }
@@ -498,7 +531,7 @@ extern "C" int sc_cast_transpose_batched(const float* master, const void* mirror
 
 static int ln_fwd_launch(const float* x, long long ldx, const float* gamma, const float* beta, void* y, long long ldy,
                          float* mean, float* rstd, int rows, int d, float eps, void* y8, long long ldy8, float* scale_inv,
-                         void* stream, bool xb = false) {
+                         void* stream, bool xb = false, const LnT8 t8 = LnT8()) {
     SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_fwd: bad shape rows=%d d=%d", rows, d);
     SC_CHECK((ldx % 4) == 0 && (ldy % 4) == 0, "sc_layernorm_fwd: row strides must be multiples of 4");
     SC_CHECK(y8 == nullptr || (scale_inv != nullptr && (ldy8 % 4) == 0 && ldy8 >= d),
@@ -508,7 +541,7 @@ static int ln_fwd_launch(const float* x, long long ldx, const float* gamma, cons
     do {                                                                                                                  \
         if (xb) {                                                                                                         \
             if (y8) ln_fwd_kernel<NV, true, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                       \
-                x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, (unsigned char*)y8, ldy8, scale_inv);       \
+                x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, (unsigned char*)y8, ldy8, scale_inv, t8);   \
             else ln_fwd_kernel<NV, false, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                         \
                 x, ldx, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, d, eps, nullptr, 0, nullptr);                       \
         } else if (y8) ln_fwd_kernel<NV, true><<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(                          \
@@ -543,6 +576,19 @@ extern "C" int sc_layernorm_fwd_x16(const void* x_bf16, long long ldx, const flo
                          true);
 }
 
+extern "C" int sc_layernorm_fwd_x16_t8(const void* x_bf16, long long ldx, const float* gamma, const float* beta, void* y,
+                                       long long ldy, void* y_fp8, long long ldy8, float* scale_inv, void* y_t8, long long ldt8,
+                                       const float* t_scale, float* t_amax, float* mean, float* rstd, int rows, int d, float eps,
+                                       void* stream) {
+    SC_CHECK(x_bf16 != nullptr && y_fp8 != nullptr, "sc_layernorm_fwd_x16_t8: bf16 input rows and the per-row e4m3 output are required");
+    SC_CHECK(y_t8 != nullptr && t_scale != nullptr && t_amax != nullptr && (ldt8 % 4) == 0 && ldt8 >= d,
+             "sc_layernorm_fwd_x16_t8: per-tensor e4m3 output needs its scale, 64 amax slots and a row stride %% 4 == 0 (ldt8=%lld)", ldt8);
+    LnT8 t8;
+    t8.t8 = (unsigned char*)y_t8; t8.ldt8 = ldt8; t8.t_scale = t_scale; t8.t_amax = t_amax;
+    return ln_fwd_launch((const float*)x_bf16, ldx, gamma, beta, y, ldy, mean, rstd, rows, d, eps, y_fp8, ldy8, scale_inv, stream,
+                         true, t8);
+}
+
 extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
     int nblk = (rows + 3) / 4;
     if (nblk > 1024) nblk = 1024;
@@ -553,7 +599,8 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
                          const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
                          long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum, float* ws, int rows,
                          int d, void* d8, long long ldd8, float* scale_inv, void* stream,
-                         const void* gin = nullptr, long long ldgin = 0, int write_f32 = 1, bool xb = false) {
+                         const void* gin = nullptr, long long ldgin = 0, int write_f32 = 1, bool xb = false,
+                         const LnT8 t8 = LnT8()) {
     SC_CHECK(rows > 0 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_layernorm_bwd: bad shape rows=%d d=%d", rows, d);
     SC_CHECK(ws != nullptr, "sc_layernorm_bwd: workspace required");
     SC_CHECK(d8 == nullptr || (scale_inv != nullptr && (ldd8 % 4) == 0 && ldd8 >= d),
@@ -571,7 +618,7 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
         ln_bwd_kernel<NV, Q, G, I><<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres,      \
                                                            lddres, (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate,    \
                                                            (unsigned char*)d8, ldd8, scale_inv, (const bf16*)gin,       \
-                                                           ldgin, write_f32);                                           \
+                                                           ldgin, write_f32, t8);                                       \
     } while (0)
 #define SC_LN_BWD_Q(NV, Q, G)                                                                                           \
     do {                                                                                                                \
@@ -633,6 +680,23 @@ extern "C" int sc_layernorm_bwd_x16(const void* dy, long long lddy, const void* 
              "sc_layernorm_bwd_x16: an incoming gradient or an fp32 output needs its buffer");
     return ln_bwd_launch(dy, lddy, (const float*)x_bf16, ldx, mean, rstd, gamma, dres, lddres, gout_bf16, ldgout, accumulate,
                          dgamma, dbeta, colsum, ws, rows, d, gout_fp8, ldd8, scale_inv, stream, gin_bf16, ldgin, write_f32, true);
+}
+
+extern "C" int sc_layernorm_bwd_x16_t8(const void* dy, long long lddy, const void* x_bf16, long long ldx, const float* mean,
+                                       const float* rstd, const float* gamma, const void* gin_bf16, long long ldgin,
+                                       float* dres, long long lddres, int write_f32, void* gout_bf16, long long ldgout,
+                                       void* gout_fp8, long long ldd8, float* scale_inv, void* gout_t8, long long ldt8,
+                                       const float* t_scale, float* t_amax, int accumulate, float* dgamma, float* dbeta,
+                                       float* colsum, float* ws, int rows, int d, void* stream) {
+    SC_CHECK(x_bf16 != nullptr && (ldx % 4) == 0 && gout_fp8 != nullptr, "sc_layernorm_bwd_x16_t8: bf16 input rows and the per-row e4m3 output are required");
+    SC_CHECK(gout_t8 != nullptr && t_scale != nullptr && t_amax != nullptr && (ldt8 % 4) == 0 && ldt8 >= d,
+             "sc_layernorm_bwd_x16_t8: per-tensor e4m3 output needs its scale, 64 amax slots and a row stride %% 4 == 0 (ldt8=%lld)", ldt8);
+    SC_CHECK((accumulate == 0 && !write_f32) || gin_bf16 != nullptr || dres != nullptr,
+             "sc_layernorm_bwd_x16_t8: an incoming gradient or an fp32 output needs its buffer");
+    LnT8 t8;
+    t8.t8 = (unsigned char*)gout_t8; t8.ldt8 = ldt8; t8.t_scale = t_scale; t8.t_amax = t_amax;
+    return ln_bwd_launch(dy, lddy, (const float*)x_bf16, ldx, mean, rstd, gamma, dres, lddres, gout_bf16, ldgout, accumulate,
+                         dgamma, dbeta, colsum, ws, rows, d, gout_fp8, ldd8, scale_inv, stream, gin_bf16, ldgin, write_f32, true, t8);
 }
 
 extern "C" int sc_layernorm_bwd_reduce(const float* ws, int rows, int d, float* dgamma, float* dbeta, float* colsum,

@@ -179,16 +179,38 @@ def attn_bwd(qkv, out, dout, lse, B: int, L: int, H: int, dh: int, causal: bool 
 
 
 # ------------------------------------------------------------------------------------------ norms
+def _t8_args(t8, rows: int, d: int, what: str):
+    """(buffer uint8 [rows, >= d], scale fp32 [1], amax fp32 [64]) -> ctypes arguments of a per-tensor e4m3 second output."""
+    buf, scale, amax = t8
+    if buf.dtype != torch.uint8 or not buf.is_cuda or buf.stride(-1) != 1 or buf.shape[0] < rows or buf.shape[1] < d:
+        raise TypeError(f"{what}: t8 buffer must be a device uint8 matrix of at least [{rows}, {d}]")
+    _req(scale, torch.float32, "t8 scale"); _req(amax, torch.float32, "t8 amax")
+    if scale.numel() != 1 or amax.numel() != 64:
+        raise ValueError(f"{what}: t8 needs a one-element scale and 64 amax slots")
+    return buf.data_ptr(), buf.stride(0), scale.data_ptr(), amax.data_ptr()
+
+
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows: int, d: int, ldx: Optional[int] = None,
                   ldy: Optional[int] = None, eps: float = 1e-5, q8: Optional[torch.Tensor] = None,
-                  q8_scale_inv: Optional[torch.Tensor] = None):
+                  q8_scale_inv: Optional[torch.Tensor] = None, t8=None):
     """``q8`` (uint8 [rows, d]) + ``q8_scale_inv`` (fp32 [rows]): also emit the e4m3 copy of the output with its
-    per-row power-of-two scale (the fp8 forward GEMM's A operand) from the same kernel."""
+    per-row power-of-two scale (the fp8 forward GEMM's A operand) from the same kernel.  ``t8`` = (uint8 [rows, d], scale
+    [1], amax [64]): a SECOND e4m3 copy with one delayed scale for the whole tensor (the e4m3 weight gradient's X operand;
+    bf16 rows + q8 only)."""
     _req(y, torch.bfloat16, "y")
     if q8 is not None:
         if q8.dtype != torch.uint8 or not q8.is_cuda or q8.stride(-1) != 1:
             raise TypeError("layernorm_fwd: q8 must be a device uint8 matrix")
         _req(q8_scale_inv, torch.float32, "q8_scale_inv")
+    if t8 is not None and (x.dtype != torch.bfloat16 or q8 is None):
+        raise _lib.SpatialClipHipError("layernorm_fwd: the per-tensor e4m3 copy exists for bf16 rows with the per-row copy (q8)")
+    if x.dtype == torch.bfloat16 and t8 is not None:
+        tp, tld, tsc, tam = _t8_args(t8, rows, d, "layernorm_fwd")
+        check(_lib.lib().sc_layernorm_fwd_x16_t8(x.data_ptr(), ldx if ldx is not None else d, gamma.data_ptr(), beta.data_ptr(),
+                                                 y.data_ptr(), ldy if ldy is not None else d, q8.data_ptr(), q8.stride(0),
+                                                 q8_scale_inv.data_ptr(), tp, tld, tsc, tam, _ptr(mean), _ptr(rstd), rows, d, eps,
+                                                 _stream()), "sc_layernorm_fwd_x16_t8")
+        return y
     if x.dtype == torch.bfloat16:           # residual stream kept in bf16 (EPI_BF16_BIAS_RES)
         _req(x, torch.bfloat16, "x")
         check(_lib.lib().sc_layernorm_fwd_x16(x.data_ptr(), ldx if ldx is not None else d, gamma.data_ptr(), beta.data_ptr(),
@@ -221,7 +243,7 @@ def gelu_bf16(u: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, colsum, rows: int, d: int, *,
                   accumulate, lddy=None, ldx=None, lddres=None, lddbf=None, ws=None, defer_reduce: bool = False,
                   q8: Optional[torch.Tensor] = None, q8_scale_inv: Optional[torch.Tensor] = None,
-                  g_in: Optional[torch.Tensor] = None, ldgin=None, write_f32: bool = True, g16: bool = False):
+                  g_in: Optional[torch.Tensor] = None, ldgin=None, write_f32: bool = True, g16: bool = False, t8=None):
     """``accumulate``: False / True, or a negative int -P: only rows r % P == 0 of ``dres`` carry an incoming gradient.
     ``defer_reduce``: leave the per-block partial sums of dgamma / dbeta / colsum in ``ws`` (caller-owned, at least
     layernorm_bwd_ws_floats floats) and finish them with layernorm_bwd_reduce -- e.g. on the weight-gradient stream.
@@ -245,6 +267,17 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dres_bf16, dgamma, dbeta, cols
             _req(dres_bf16, torch.bfloat16, "dres_bf16")
         if q8 is not None:
             _req(q8_scale_inv, torch.float32, "q8_scale_inv")
+        if t8 is not None:
+            if not xb or q8 is None:
+                raise _lib.SpatialClipHipError("layernorm_bwd: the per-tensor e4m3 copy exists for bf16 rows with the per-row copy (q8)")
+            tp, tld, tsc, tam = _t8_args(t8, rows, d, "layernorm_bwd")
+            check(l.sc_layernorm_bwd_x16_t8(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
+                                            gamma.data_ptr(), _ptr(g_in), ldgin or d, dres.data_ptr(), lddres or d, int(write_f32),
+                                            _ptr(dres_bf16), lddbf or d, q8.data_ptr(), q8.stride(0), q8_scale_inv.data_ptr(),
+                                            tp, tld, tsc, tam, int(accumulate), None if defer_reduce else dgamma.data_ptr(),
+                                            dbeta.data_ptr(), _ptr(colsum), ws.data_ptr(), rows, d, _stream()),
+                  "sc_layernorm_bwd_x16_t8")
+            return
         fn = l.sc_layernorm_bwd_x16 if xb else l.sc_layernorm_bwd_g16
         check(fn(dy.data_ptr(), lddy or d, x.data_ptr(), ldx or d, mean.data_ptr(), rstd.data_ptr(),
                                      gamma.data_ptr(), _ptr(g_in), ldgin or d, dres.data_ptr(), lddres or d, int(write_f32),

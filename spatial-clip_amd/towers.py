@@ -120,8 +120,13 @@ class TransformerStack:
         # a fresh eval process and an in-fit validation of the same weights give the same numbers (advisor, round 3)
         self.fp8_train_pass = True
         self._dq_step = 0
+        # e4m3 weight gradients of the MLP pair (round 4, sc_gemm_wgrad_fp8): their operands need ONE scale per tensor -- h and
+        # dU have such copies already (entries 2 i, 2 i + 1); the LayerNorm kernels add per-tensor copies of a2 = ln_2(x) and of
+        # the residual gradient g0 that enters the block's MLP branch (entries 2 L + 2 i, 2 L + 2 i + 1).  SC_FP8_WGRAD=0: A/B.
+        self._w8_on = os.environ.get("SC_FP8_WGRAD", "1") != "0"
+        self._fwd_w8 = False
         if self.fp8:
-            n = 2 * layers
+            n = 4 * layers
             self._dq_scale = torch.zeros(n, dtype=F32, device=store.device)
             self._dq_scale_inv = torch.ones(n, dtype=F32, device=store.device)
             self._dq_amax = torch.zeros((n, 64), dtype=F32, device=store.device)
@@ -205,6 +210,10 @@ class TransformerStack:
         x = x0
         if r16:                                       # the stem writes fp32: one cast pass per step
             x = ops.cast_pad_bf16(x0, bf.get("x0.16", (M, d), BF16), M, d, d)
+        # e4m3 MLP weight gradients: only for a pass that will be differentiated, on the bf16 stream (the per-tensor LayerNorm
+        # copies exist for bf16 rows), without recomputation (h8 is not rebuilt), token count a multiple of the 128-token K tile
+        use_w8 = self._fwd_w8 = bool(self.fp8 and self._dq_on and self._w8_on and self.fp8_train_pass and r16 and not self.recompute
+                                     and M % 128 == 0 and d % 16 == 0 and mlp % 16 == 0 and d >= 256)
         self.x_in = [None] * self.layers
         for i in range(self.layers):
             self.x_in[i] = x
@@ -228,8 +237,12 @@ class TransformerStack:
             a2 = self._act("a2", i, (M, d))
             m2 = bf.get(f"m2.{i}", (M,), F32)
             r2 = bf.get(f"r2.{i}", (M,), F32)
+            t8a = None
+            if use_w8:      # per-tensor e4m3 copy of a2, kept per block: X operand of the e4m3 c_fc weight gradient
+                ia = 2 * self.layers + 2 * i
+                t8a = (bf.get(f"t8.a2.{i}", (M, d), torch.uint8), self._dq_scale[ia:ia + 1], self._dq_amax[ia])
             ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2, m2, r2, M, d,
-                              q8=qa and qa[0], q8_scale_inv=qa and qa[1])
+                              q8=qa and qa[0], q8_scale_inv=qa and qa[1], t8=t8a)
             # the MLP's backward needs gelu'(u), not u: the default path stores that factor (the forward epilogue holds the
             # erf pieces anyway) and the c_proj data gradient becomes one multiply; recomputation mode keeps u, from which
             # it rebuilds h = gelu(u)
@@ -239,7 +252,7 @@ class TransformerStack:
             self._u_holds_grad = not self.recompute        # what THIS forward left in the u buffers (read by backward)
             hq = None
             if self.fp8 and self._dq_on and self.fp8_train_pass:      # the GELU epilogue also emits e4m3(h) with last step's scale + records max|h|
-                h8 = bf.get("q8.h", (M, mlp), torch.uint8)
+                h8 = bf.get(f"q8.h.{i}" if use_w8 else "q8.h", (M, mlp), torch.uint8)     # kept per block when the weight gradient reads it
                 hq = dict(q8_out=h8, q8_scale=self._dq_scale[2 * i:2 * i + 1], q8_amax=self._dq_amax[2 * i])
             self._linear_fwd(epi_gelu, a2, self._n(i, "mlp.c_fc.weight"), u,
                              M=M, N=mlp, K=d, bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h, q8=qa, **(hq or {}))
@@ -323,11 +336,16 @@ class TransformerStack:
         dres_bf = bf.get("dres_bf.0", (M, d), BF16)
         prev_bias = s.g(self._n(i - 1, "mlp.c_proj.bias")) if i > 0 else None
         qg = self._q8("g", M, d)
+        t8g = None
+        if self._fwd_w8 and i > 0 and qg is not None and _res_grad_bf16():     # per-tensor e4m3 copy: dY of block i - 1's c_proj weight gradient
+            ig = 2 * self.layers + 2 * (i - 1) + 1
+            t8g = (bf.get("t8.g.0", (M, d), torch.uint8), self._dq_scale[ig:ig + 1], self._dq_amax[ig])
         ops.layernorm_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
                           s.p(self._n(i, "ln_1.weight")), dres, dres_bf, g("ln_1.weight"), g("ln_1.bias"),
                           prev_bias, M, d, accumulate=-L,       # only the class-token rows carry a residual gradient
                           q8=qg and qg[0], q8_scale_inv=qg and qg[1],
-                          g16=_res_grad_bf16(), write_f32=(i == 0))  # bf16 stream: fp32 only in front of the stem
+                          g16=_res_grad_bf16(), write_f32=(i == 0), t8=t8g)  # bf16 stream: fp32 only in front of the stem
+        self._g_t8_ok = t8g is not None
         self._g_q8 = qg
         return dres, dres_bf
 
@@ -393,10 +411,12 @@ class TransformerStack:
         # stem reads it).  SC_RES_GRAD=fp32 keeps the fp32 read-modify-write of rounds 1-2 (16 instead of 10 bytes per element).
         g16 = _res_grad_bf16() and self.res16_ok      # text tower: fp32 stream AND fp32 residual gradient, as the reference's
 
-        def ln_bwd(dy, x, mean, rstd, gamma, g_in, g_bf, dgamma, dbeta, colsum, last=False) -> None:
+        def ln_bwd(dy, x, mean, rstd, gamma, g_in, g_bf, dgamma, dbeta, colsum, last=False, t8=None) -> None:
             kw = dict(q8=qg[0], q8_scale_inv=qg[1]) if qg is not None else {}
             if g16:
                 kw.update(g16=True, g_in=g_in, write_f32=last)
+            if t8 is not None:
+                kw.update(t8=t8)
             if not overlap:
                 ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, g_bf, dgamma, dbeta, colsum, M, d, accumulate=True, **kw)
                 return
@@ -431,6 +451,11 @@ class TransformerStack:
                 on_side(lambda: on_layer_done(self.layers - 1), ())
         ring = [dres_bf, bf.get("dres_bf.1", (M, d), BF16), bf.get("dres_bf.2", (M, d), BF16)]
         rpos = 0
+        # e4m3 MLP weight gradients: per-tensor copies of the residual gradient travel beside the bf16 ring (same slots)
+        w8 = bool(self._fwd_w8 and g16 and qg is not None)
+        t8ring = [bf.get(f"t8.g.{k}", (M, d), torch.uint8) for k in range(3)] if w8 else None
+        g0_t8_ok = w8 and self.cls_only_last and getattr(self, "_g_t8_ok", False)      # does t8ring[rpos] hold the copy of ring[rpos]?
+        L2 = 2 * self.layers
         for i in reversed(range(top)):
             g = lambda leaf, i=i: s.g(self._n(i, leaf))
             cp = lambda leaf, i=i: s.copies[self._n(i, leaf)]
@@ -447,7 +472,8 @@ class TransformerStack:
             before_write(dU)
             dq = None
             if self.fp8 and self._dq_on:      # GELU' epilogue: e4m3(dU) with last step's scale + max|dU| for the next one
-                dU8 = bf.get("q8.dU", (M, mlp), torch.uint8)
+                dU8 = bf.get(f"q8.dU.{i & 1}" if w8 else "q8.dU", (M, mlp), torch.uint8)     # rotates with dU when the side stream reads it
+                before_write(dU8)
                 dq = dict(q8_out=dU8, q8_scale=self._dq_scale[2 * i + 1:2 * i + 2], q8_amax=self._dq_amax[2 * i + 1])
             dU_has_q8 = bool(dq) and g_has_q8 and self._dq_ready
             # aux = the stored factor gelu'(u) (default) or u itself (recomputation mode): same bits either way
@@ -456,7 +482,21 @@ class TransformerStack:
 
             mlp_probs = [(g0, h, g("mlp.c_proj.weight"), None, d, mlp), (dU, a2, g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), mlp, d)]
 
-            def w_mlp(g0=g0, h=h, dU=dU, a2=a2, g=g, probs=mlp_probs):
+            # e4m3 weight gradients of the MLP pair: every operand has a per-tensor copy made with scales that were ready when the
+            # forward ran (h8 / a2 by the forward, dU8 / g0 by this backward); the first step after a reset stays in bf16
+            w8_now = bool(w8 and self._dq_ready and dq is not None and g0_t8_ok and g_has_q8)
+            g0_8 = t8ring[rpos] if w8_now else None
+
+            def w_mlp(g0=g0, h=h, dU=dU, a2=a2, g=g, probs=mlp_probs, i=i, w8_now=w8_now, g0_8=g0_8, dU8=(dU8 if dq else None)):
+                if w8_now:
+                    sinv = self._dq_scale_inv
+                    ops.gemm_wgrad_fp8(g0_8, sinv[L2 + 2 * i + 1:L2 + 2 * i + 2], bf.get(f"q8.h.{i}", (M, mlp), torch.uint8),
+                                       sinv[2 * i:2 * i + 1], g("mlp.c_proj.weight"), None, M=d, N=mlp, K=M,
+                                       splitk=_splitk_for(d, mlp, M))
+                    ops.gemm_wgrad_fp8(dU8, sinv[2 * i + 1:2 * i + 2], bf.get(f"t8.a2.{i}", (M, d), torch.uint8),
+                                       sinv[L2 + 2 * i:L2 + 2 * i + 1], g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), M=mlp, N=d, K=M,
+                                       splitk=_splitk_for(mlp, d, M))
+                    return
                 if _group_ok(wg_mode, "mlp", [(d, mlp), (mlp, d)], M):      # both weight gradients of the MLP branch in one launch
                     ops.gemm_wgrad_group(probs, K=M, splitk=_splitk_for_group([(d, mlp), (mlp, d)], M, one_round=wg_mode != "2"))
                     return
@@ -470,7 +510,10 @@ class TransformerStack:
                 ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
                                   bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32), M, d)
             if wg_mode != "4":
-                on_side(w_mlp, (g0, dU, h, a2) if self.recompute else (g0, dU))
+                reads_mlp = (g0, dU, h, a2) if self.recompute else (g0, dU)
+                if w8_now:
+                    reads_mlp = reads_mlp + (g0_8, dU8)
+                on_side(w_mlp, reads_mlp)
             cfc = cp("mlp.c_fc.weight")
             if dU_has_q8 and cfc.wb8 is not None:
                 ops.gemm_fp8(ops.EPI_BF16, dU8, self._dq_scale_inv[2 * i + 1:2 * i + 2], cfc.wb8, cfc.wb8s, dA, M=M, N=d, K=mlp,
@@ -515,9 +558,15 @@ class TransformerStack:
             rpos = (rpos + 1) % 3
             g2 = ring[rpos]
             before_write(g2)
+            t8n = None
+            if w8 and i > 0:        # g2 is block i - 1's g0: its per-tensor e4m3 copy, in the ring slot beside it
+                before_write(t8ring[rpos])
+                ig = L2 + 2 * (i - 1) + 1
+                t8n = (t8ring[rpos], self._dq_scale[ig:ig + 1], self._dq_amax[ig])
             ln_bwd(dA, self.x_in[i], bf.get(f"m1.{i}", (M,), F32), bf.get(f"r1.{i}", (M,), F32),
-                   s.p(self._n(i, "ln_1.weight")), g1, g2, g("ln_1.weight"), g("ln_1.bias"), prev_bias, last=(i == 0))
+                   s.p(self._n(i, "ln_1.weight")), g1, g2, g("ln_1.weight"), g("ln_1.bias"), prev_bias, last=(i == 0), t8=t8n)
             g_has_q8 = qg is not None
+            g0_t8_ok = t8n is not None
             if on_layer_done is not None:
                 on_side(lambda i=i: on_layer_done(i), ())     # the bucket all-reduce follows the side stream
         if self.fp8 and self._dq_on:          # next step's per-tensor scales from the maxima of the last FP8_AMAX_HISTORY steps

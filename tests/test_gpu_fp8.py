@@ -406,3 +406,53 @@ def test_wgrad_fp8_exact_on_representable_data(M, N, K, splitk, bias):
         assert torch.equal(dw.cpu(), 2.0 * (dy.t() @ x)), (M, N, K, splitk, rep)
         if bias:
             assert torch.equal(db.cpu(), 0.5 * dy.sum(0)), (M, N, K, splitk, rep, "bias")
+
+
+def test_e4m3_mlp_weight_gradients_in_the_model(monkeypatch):
+    """Round 4: with ``precision="fp8"`` the c_fc / c_proj WEIGHT gradients of the full-width blocks run on sc_gemm_wgrad_fp8 once
+    the delayed scales are ready (operands: per-tensor e4m3 copies of h, dU, a2 = ln_2(x) and of the residual gradient).  Same
+    weights, same batch, second step (the first primes the scales), against the same model with ``SC_FP8_WGRAD=0`` (those four
+    GEMM operands in bf16): every other gradient is bit-identical, the MLP weight / bias gradients of the full-width blocks agree
+    to e4m3 noise, and both stay within the fp8 path's stated distance of the fp32 oracle."""
+    import functools
+    from oracle import spatial_clip_oracle as O
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data, losses, model_configs as mc, module, net, optim
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 256, 3, 64), text=None, gene=mc.GeneCfg(200, 64))
+    ocfg = O.ModelCfg(embed_dim=64, vision=O.VisionCfg(32, 8, 256, 3, 64), text=None, gene=O.GeneCfg(200, 64))
+    B = 128                                        # 128 x 17 tokens = 17 K tiles of 128 tokens
+    batch = data.synthetic_batch(B, 32, 200, K=4, step=0)
+    db = {k: v.cuda() for k, v in batch.items()}
+    grads, used = {}, {}
+    for tag, env in (("w8", "1"), ("ref", "0")):
+        monkeypatch.setenv("SC_FP8_WGRAD", env)
+        n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=9, precision="fp8")
+        m = module.SpatialClipLitModule(
+            n, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True),
+            functools.partial(optim.FusedAdamW, lr=0.0, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.0),
+            functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+
+        class T:
+            max_steps, max_epochs, estimated_stepping_batches = 20, None, 20
+        m.trainer = T()
+        for step in range(2):                      # lr = 0: the weights stay the initial ones; step 0 records the maxima
+            loss = m.training_step(db, step)
+            loss.backward()
+        torch.cuda.synchronize()
+        used[tag] = n.vision.stack._fwd_w8
+        grads[tag] = {k: n.store.g(k).detach().cpu().clone() for k in n.state_dict()}
+        params = {k: v.cpu() for k, v in n.state_dict().items()}
+    assert used["w8"] and not used["ref"]
+    mlp_full = [f"visual.transformer.resblocks.{i}.mlp.{leaf}" for i in range(2) for leaf in ("c_fc.weight", "c_fc.bias", "c_proj.weight")]
+    for k in grads["ref"]:
+        if k in mlp_full:
+            rel = float((grads["w8"][k] - grads["ref"][k]).norm() / grads["ref"][k].norm())
+            assert rel < 0.08, (k, rel)
+        else:
+            assert torch.equal(grads["w8"][k], grads["ref"][k]), k
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f = O.net_forward(batch["images"], batch["texts"], p, ocfg)
+    O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"]).backward()
+    for k in mlp_full:
+        e = float((grads["w8"][k] - p[k].grad).abs().max() / p[k].grad.abs().max())
+        assert e < 0.35, (k, e)
