@@ -211,8 +211,10 @@ class TransformerStack:
         if r16:                                       # the stem writes fp32: one cast pass per step
             x = ops.cast_pad_bf16(x0, bf.get("x0.16", (M, d), BF16), M, d, d)
         # e4m3 MLP weight gradients: only for a pass that will be differentiated, on the bf16 stream (the per-tensor LayerNorm
-        # copies exist for bf16 rows), without recomputation (h8 is not rebuilt), token count a multiple of the 128-token K tile
-        use_w8 = self._fwd_w8 = bool(self.fp8 and self._dq_on and self._w8_on and self.fp8_train_pass and r16 and not self.recompute
+        # copies exist for bf16 rows), token count a multiple of the 128-token K tile.  With activation recomputation the e4m3
+        # copies of h and a2 are KEPT per block (1 + 0.25 bytes per MLP element instead of the 2 + 0.5 of the bf16 tensors that
+        # recomputation drops), and the backward then has nothing to rebuild for the MLP branch
+        use_w8 = self._fwd_w8 = bool(self.fp8 and self._dq_on and self._w8_on and self.fp8_train_pass and r16
                                      and M % 128 == 0 and d % 16 == 0 and mlp % 16 == 0 and d >= 256)
         self.x_in = [None] * self.layers
         for i in range(self.layers):
@@ -503,14 +505,14 @@ class TransformerStack:
                 ops.gemm(ops.TN, ops.EPI_F32, g0, h, g("mlp.c_proj.weight"), M=d, N=mlp, K=M, splitk=_splitk_for(d, mlp, M))
                 ops.gemm_wgrad_bias(dU, a2, g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), M=mlp, N=d, K=M,
                                     splitk=_splitk_for(mlp, d, M))
-            if self.recompute:          # rebuild h = gelu(u) and a2 = ln_2(xmid) for the two weight gradients
+            if self.recompute and not w8_now:          # rebuild h = gelu(u) and a2 = ln_2(xmid) for the two (bf16) weight gradients
                 before_write(h)
                 ops.gelu_bf16(u, h)
                 before_write(a2)
                 ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
                                   bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32), M, d)
             if wg_mode != "4":
-                reads_mlp = (g0, dU, h, a2) if self.recompute else (g0, dU)
+                reads_mlp = (g0, dU, h, a2) if (self.recompute and not w8_now) else (g0, dU)
                 if w8_now:
                     reads_mlp = reads_mlp + (g0_8, dU8)
                 on_side(w_mlp, reads_mlp)
