@@ -568,8 +568,11 @@ SC_DEVICE void tn_read(unsigned base, const unsigned (&off)[NF], FragTN (&f)[2 *
 }
 
 struct StagerTN {
-    const bf16* src[4][2];
-    long long step[4];          // elements per K tile (64 source rows) for each half-tile kind
+    // wave-uniform base (SGPRs) + 32-bit per-lane byte offset: the DMA takes the scalar-base addressing form (no address VALU, 4
+    // VGPRs instead of 16); piece 1 of a half-tile is 32 k rows behind piece 0 = a scalar addend (round 4, from the e4m3 kernel)
+    const char* base[4];
+    unsigned off[4];
+    long long step[4];          // BYTES per K tile (64 source rows) for each half-tile kind
     int nt;
     int wave;
 };
@@ -586,8 +589,11 @@ SC_DEVICE void phase_tn(char* smem, unsigned lds0, const StagerTN& S, int t, con
     constexpr int DS = PH <= 2 ? (D ^ 1) : D;
     const int ts = t + (PH <= 2 ? 1 : 2);
     if (ts < S.nt) {
-        dma16(S.src[q][0] + ts * S.step[q], smem + slot(DS, q) + S.wave * 1024);
-        dma16(S.src[q][1] + ts * S.step[q], smem + slot(DS, q) + (8 + S.wave) * 1024);
+        const char* kb = S.base[q] + ts * S.step[q];
+        unsigned o0 = S.off[q];
+        asm volatile("" : "+v"(o0));                      // keep (scalar base + 32-bit offset): no hoisted 64-bit sums
+        dma16(kb + o0, smem + slot(DS, q) + S.wave * 1024);
+        dma16(kb + (S.step[q] >> 1) + o0, smem + slot(DS, q) + (8 + S.wave) * 1024);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -655,20 +661,22 @@ SC_DEVICE void tn_tile(const GemmArgs& g, int idx, char* smem) {
     StagerTN S;
     S.nt = (kend - kbeg) / BK;
     S.wave = wave;
-    S.step[0] = S.step[3] = (long long)BK * g.lda;
-    S.step[1] = S.step[2] = (long long)BK * g.ldb;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int kr = p * 32 + wave * 4 + (lane >> 4);                 // k row of the half-tile image, 256 B per row
+    S.step[0] = S.step[3] = (long long)BK * g.lda * 2;
+    S.step[1] = S.step[2] = (long long)BK * g.ldb * 2;
+    {
+        // piece p = k rows [32 p + 4 wave, + 4): rows kr and kr + 32 share the swizzle term (bits 0, 1, 3 of k)
+        const int kr = wave * 4 + (lane >> 4);                          // k row of the half-tile image, 256 B per row
         const int s = (kr & 3) | (((kr >> 3) & 1) << 2);
         const int c = ((((lane & 15) >> 1) ^ s) << 4) + (lane & 1) * 8;  // logical column held at physical lane&15
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ca = min(m0 + h * 128 + c, g.M - 8), cb = min(n0 + h * 128 + c, g.N - 8);
-            S.src[h ? 3 : 0][p] = g.A + (size_t)(kbeg + kr) * g.lda + ca;
-            S.src[h ? 2 : 1][p] = g.B + (size_t)(kbeg + kr) * g.ldb + cb;
+            S.off[h ? 3 : 0] = ((unsigned)kr * (unsigned)g.lda + (unsigned)ca) * 2u;
+            S.off[h ? 2 : 1] = ((unsigned)kr * (unsigned)g.ldb + (unsigned)cb) * 2u;
         }
     }
+    S.base[0] = S.base[3] = reinterpret_cast<const char*>(g.A + (size_t)kbeg * g.lda);
+    S.base[1] = S.base[2] = reinterpret_cast<const char*>(g.B + (size_t)kbeg * g.ldb);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
     unsigned a_off[4], b_off[2];
     {
@@ -693,8 +701,9 @@ SC_DEVICE void tn_tile(const GemmArgs& g, int idx, char* smem) {
     for (int s = 0; s < 6; ++s) {
         const int ts = s >> 2, q = s & 3;
         if (ts < S.nt) {
-            dma16(S.src[q][0] + ts * S.step[q], smem + slot(ts & 1, q) + wave * 1024);
-            dma16(S.src[q][1] + ts * S.step[q], smem + slot(ts & 1, q) + (8 + wave) * 1024);
+            const char* kb = S.base[q] + ts * S.step[q];
+            dma16(kb + S.off[q], smem + slot(ts & 1, q) + wave * 1024);
+            dma16(kb + (S.step[q] >> 1) + S.off[q], smem + slot(ts & 1, q) + (8 + wave) * 1024);
         }
     }
     if (S.nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
