@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-head attention kernels on the ViT-L/14 shape (B=256, L=257, H=16, dh=64): plain and with the e4m3 copies, this build
-against another build of the library (SC_HIP_LIB_ALT, optional) in the same process order."""
+"""Attention forward / backward alone on the ViT-L/14 shape (B=256, L=257, H=16, dh=64): the per-head kernels (the persistent ones
+stop at L = 224)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,10 +16,6 @@ lse = torch.empty(B, H, L, device="cuda")
 dout = (torch.randn(B * L, d, device="cuda", generator=g) * 0.05).bfloat16()
 dqkv = torch.empty_like(qkv)
 delta = torch.empty(B, H, L, device="cuda")
-o8 = torch.empty(B * L, d, device="cuda", dtype=torch.uint8)
-d8 = torch.empty(B * L, 3 * d, device="cuda", dtype=torch.uint8)
-s1, a1 = torch.tensor([64.0], device="cuda"), torch.zeros(64, device="cuda")
-s3, a3 = torch.tensor([2048.0, 4096.0, 256.0], device="cuda"), torch.zeros(3, 64, device="cuda")
 n = int(os.environ.get("N", 20))
 
 
@@ -37,6 +33,4 @@ def timeit(fn, name):
 
 for rep in range(int(os.environ.get("REPS", 2))):
     timeit(lambda: ops.attn_fwd(qkv, B, L, H, dh, False, out=out, lse=lse), "fwd")
-    timeit(lambda: ops.attn_fwd(qkv, B, L, H, dh, False, out=out, lse=lse, t8=(o8, s1, a1)), "fwd + e4m3 copy")
     timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, dh, False, dqkv=dqkv, delta=delta), "bwd")
-    timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, dh, False, dqkv=dqkv, delta=delta, t8=(d8, s3, a3)), "bwd + e4m3 copies")
