@@ -323,6 +323,19 @@ def main():
                                           args.loss, args.dtype, "initial weights, benchmark batch 0")
         note(f"init-point loss delta {delta_init['loss_delta_vs_oracle']:.2e}, max feature delta "
              f"{delta_init['max_abs_feature_delta']:.2e} (bound {delta_init['tolerance']:g})")
+    # Setup before the warm-up: with SC_OVERLAP unset ("auto") every transformer stack times its own backward with the
+    # weight gradients on the side stream and on the chain stream (towers.TransformerStack._overlap_auto: 2 + 4 + 4 calls, one more
+    # to decide) and keeps the faster schedule -- the same bits either way.  Like a kernel autotuner, this runs once per
+    # process and batch shape, and is not part of the W warm-up or the K timed steps.
+    setup_steps = 0
+    if os.environ.get("SC_OVERLAP", "auto") not in ("0", "1"):
+        from spatial_clip_amd import towers as _towers
+        setup_steps = sum(_towers.TransformerStack.OVERLAP_TRIAL_CALLS[1:]) * 2 + _towers.TransformerStack.OVERLAP_TRIAL_CALLS[0] + 1
+        note(f"schedule selection ({setup_steps} steps)")
+        for i in range(setup_steps):
+            step(i)
+        torch.cuda.synchronize()
+        note(f"weight-gradient side stream per stack: {n.side_stream_choice()}")
     note(f"model + {len(batches)} batches resident; warm-up ({args.warmup} steps)")
     for i in range(args.warmup):
         step(i)
@@ -438,7 +451,8 @@ def main():
             cpu = cpu_baseline(args.model, args.n_genes)
             note("cpu baseline done")
         out = {"metric": "tile-gene pairs/sec (train step)", "value": round(value, 2), "unit": "pairs/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_steps": setup_steps,
+               "side_stream": n.side_stream_choice() if setup_steps else os.environ.get("SC_OVERLAP"),
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"{args.model} image tower + " + (

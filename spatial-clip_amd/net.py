@@ -196,6 +196,15 @@ class SpatialClipNet(torch.nn.Module):
     def _stacks(self):
         return [(name, t.stack) for name, t in (("vision", self.vision), ("second", self.second)) if getattr(t, "stack", None) is not None]
 
+    def side_stream_choice(self) -> Dict[str, Optional[bool]]:
+        """Per transformer stack: the weight-gradient schedule ``SC_OVERLAP=auto`` settled on for the batch shape of the last
+        backward (True = side stream, False = one stream, None = still measuring, or pinned by SC_OVERLAP=0 / 1)."""
+        out = {}
+        for name, stack in self._stacks():
+            st = getattr(stack, "_ov_auto", {}).get((getattr(stack, "B", None), getattr(stack, "L", None)))
+            out[name] = None if st is None else st["choice"]
+        return out
+
     def reset_fp8_scaling(self) -> None:
         """fp8 path: drop the per-tensor scales carried from the previous steps (towers.TransformerStack.reset_fp8_scaling)."""
         for _, stack in self._stacks():

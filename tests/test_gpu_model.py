@@ -403,6 +403,40 @@ def test_side_stream_weight_gradients_are_bit_identical(monkeypatch):
         grads[mode + str(len(grads))] = g
 
 
+def test_side_stream_auto_selection_keeps_the_bits(monkeypatch):
+    """SC_OVERLAP unset = "auto": each stack times its own backward on both schedules (2 warm-up + 4 + 4 alternating calls per batch
+    shape) and keeps the faster; whatever call of the selection a step falls on, its gradients are those of the pinned
+    single-stream schedule, and after 11 calls a choice stands."""
+    data, losses, mc, module, net, optim = _pkg()
+    cfg, _ = tiny_cfgs(128, 64, 3, 48, 16)
+    B = 24
+    batch = {k: v.cuda() for k, v in data.synthetic_batch(B, 48, cfg.gene.n_genes, K=4, step=0).items()}
+
+    def grads_of(n, calls):
+        m = module.SpatialClipLitModule(n, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True), None, None)
+        out = []
+        for _ in range(calls):
+            m.model_step(batch)["loss"].backward()
+            torch.cuda.synchronize()
+            out.append({k: n.store.g(k).clone() for k in n.state_dict()})
+        return out
+
+    monkeypatch.setenv("SC_OVERLAP", "0")
+    n0 = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=3)
+    perturb(n0)
+    ref = grads_of(n0, 1)[0]
+    monkeypatch.delenv("SC_OVERLAP")
+    n1 = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=3)
+    perturb(n1)
+    assert n1.side_stream_choice()["vision"] is None
+    for i, g in enumerate(grads_of(n1, 12)):
+        for k in g:
+            assert torch.equal(g[k], ref[k]), (i, k)
+    assert n1.side_stream_choice()["vision"] in (True, False)
+    st = n1.vision.stack._ov_auto[(B, n1.vision.stack.L)]
+    assert len(st["ms"][True]) == 4 and len(st["ms"][False]) == 4 and not st["pending"]
+
+
 def test_pretrained_file_with_other_grid_is_resized(tmp_path):
     """Checkpoint interop: a local state_dict trained at another resolution loads by reference key names and gets its
     position-embedding grid resampled (model.py:792-823); every other tensor is taken as is."""
