@@ -417,7 +417,8 @@ def main():
             fo, so, co = ao[dom]
             roofline["with_side_stream"] = {"achieved": round(fo / so / 1e12, 1), "avg_launch_us": round(so / co * 1e6, 1),
                                             "instrumented_ms_per_step": round(dt_ov / args.steps * 1e3, 3),
-                                            "note": "same launches while the weight-gradient GEMMs share the chip (the shipped schedule)"}
+                                            "note": "same launches while the weight-gradient GEMMs share the chip (SC_OVERLAP=1: the schedule "
+                                                    "SC_OVERLAP=auto keeps only where it is faster, see side_stream)"}
         if "gemm_nt_fp8" in agg:
             roofline["forward_fp8"] = {"achieved": round(f8 / s8 / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
                                        "frac": round(f8 / s8 / 1e12 / 5000.0, 4), "launches_per_step": c8 // args.steps,

@@ -9,7 +9,7 @@ SC_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-los
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-kernel-events --no-loss-delta"
 SC_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o s -- $B --steps 6 --warmup 2 > $O/prof_single.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_side -o s -- $B --steps 6 --warmup 2 > $O/prof_side.log 2>&1
+SC_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_side -o s -- $B --steps 6 --warmup 2 > $O/prof_side.log 2>&1
 SC_OVERLAP=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o f -- $B --steps 3 --warmup 1 > $O/pmc_f.log 2>&1
 SC_OVERLAP=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o w -- $B --steps 3 --warmup 1 > $O/pmc_w.log 2>&1
 SC_OVERLAP=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_m -o m -- $B --steps 2 --warmup 1 > $O/pmc_m.log 2>&1
@@ -17,4 +17,4 @@ cd $R
 python tools/pmc_summary.py $(find $O/pmc_f -name "f_counter_collection.csv") $(find $O/pmc_w -name "w_counter_collection.csv") $O/pmc_traffic_summary.json > $O/pmc_traffic.txt 2>&1; head -12 $O/pmc_traffic.txt
 python tools/pmc_generic.py $O/pmc_mfma_summary.json "$O/pmc_m/**/m_counter_collection.csv" > $O/pmc_mfma.txt 2>&1; head -12 $O/pmc_mfma.txt
 find $O -name "*kernel_trace.csv" -size +20M -delete; find $O -name "*counter_collection.csv" -size +20M -delete
-find $O -name "*kernel_stats.csv"
+find $O -name "*kernel_stats.csv"; true
