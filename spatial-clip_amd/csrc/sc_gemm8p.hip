@@ -21,6 +21,8 @@
 //   fp32 LDS staging shared with sc_gemm256.hip (sc_gemm_common.h).
 #include "sc_gemm_common.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -45,8 +47,9 @@ SC_DEVICE void dma16(const void* src, char* lds_wave_base) {
 // XOR-swizzled by row so the 8-B writes (2-way at worst) and 16-B reads spread over the banks.
 //   BF16 / BF16_BIAS: C = bf16(acc (+ bias));  GELU_PAIR: C = u = bf16(acc + bias), C2 = bf16(gelu(float(u)));
 //   GELU_GRAD_PAIR: C = bf16(gelu'(float(u))), C2 as before, u itself is not stored.
-template <int EPI, bool Q8 = false>
-SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* strip, int row0, int col0, int lane) {
+template <int EPI, bool Q8 = false, bool LUT = false>
+SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* strip, int row0, int col0, int lane,
+                                 const unsigned* lut = nullptr) {
     float amax_lane = 0.f;
     const float q8s = (Q8 && sc_epi_gelu_fwd(EPI) && g.q8) ? *g.q8_scale : 0.f;
     const int li = lane & 15, lg = lane >> 4;
@@ -92,12 +95,38 @@ SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* st
                         for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_gelu_fast((float)x.h[e]);
                     } else {                             // the backward's factor gelu'(u) instead of u
                         bf16x8 gd;
+                        bool formula = true;
+                        if (LUT) {                       // both values by table (SC_GELU_LUT_*): same bits as the formula
+                            unsigned ent[8];
+                            bool inside = true;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float hv, gv;
-                            sc_gelu_both((float)x.h[e], hv, gv);
-                            o[e] = (bf16)hv;
-                            gd[e] = (bf16)gv;
+                            for (int e = 0; e < 8; ++e) {
+                                const unsigned bits = (u[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                                const unsigned rel = (bits & 0x7FFFu) - (unsigned)SC_GELU_LUT_LO;
+                                inside = inside && rel < (unsigned)SC_GELU_LUT_HALF;
+                                const unsigned idx = min(rel, (unsigned)SC_GELU_LUT_HALF - 1u) + (bits >> 15) * (unsigned)SC_GELU_LUT_HALF;
+                                ent[e] = lut[idx];
+                            }
+                            formula = __builtin_amdgcn_ballot_w64(!inside) != 0;      // wave-uniform
+                            if (!formula) {
+                                union { u32x4 w; bf16x8 h; } lo, hi;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    lo.w[q] = __builtin_amdgcn_perm(ent[2 * q + 1], ent[2 * q], 0x05040100u);
+                                    hi.w[q] = __builtin_amdgcn_perm(ent[2 * q + 1], ent[2 * q], 0x07060302u);
+                                }
+                                o = lo.h;
+                                gd = hi.h;
+                            }
+                        }
+                        if (formula) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                float hv, gv;
+                                sc_gelu_both((float)x.h[e], hv, gv);
+                                o[e] = (bf16)hv;
+                                gd[e] = (bf16)gv;
+                            }
                         }
                         *reinterpret_cast<bf16x8*>(C + (size_t)grow * g.ldc + gcol) = gd;
                     }
@@ -268,7 +297,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
 
     // Epilogue: bf16 outputs without an extra input tile go through the bf16 LDS strip (full-line stores, half the LDS
     // bytes); the fp32-residual, GELU' and fp32 epilogues keep the fp32 staging shared with sc_gemm256.hip.
-    if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || sc_epi_gelu_fwd(EPI)) {
+    if (EPI == SC_EPI_GELU_GRAD_PAIR && g.gelu_lut != nullptr) {
+        // the table moves into the dead operand ring (behind the eight 4-KiB strips) while the first strip pass is packed
+        unsigned* lut = reinterpret_cast<unsigned*>(smem + 8 * 4096);
+        for (int c = t; c < SC_GELU_LUT_N / 4; c += 512)
+            reinterpret_cast<u32x4*>(lut)[c] = reinterpret_cast<const u32x4*>(g.gelu_lut)[c];
+        __syncthreads();
+        epilogue_bf16_lds<EPI, false, true>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane, lut);
+    } else if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || sc_epi_gelu_fwd(EPI)) {
         epilogue_bf16_lds<EPI>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
     } else {
         const int mw = wr * 128;
@@ -288,6 +324,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
             __builtin_amdgcn_wave_barrier();
         }
     }
+}
+
+__global__ void sc_gelu_lut_fill_kernel(unsigned* lut) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SC_GELU_LUT_N) return;
+    const unsigned bits = (unsigned)(SC_GELU_LUT_LO + i % SC_GELU_LUT_HALF) | (i >= SC_GELU_LUT_HALF ? 0x8000u : 0u);
+    const float u = __uint_as_float(bits << 16);
+    float hv, gv;
+    sc_gelu_both(u, hv, gv);
+    union { bf16 b; unsigned short s; } h, gq;
+    h.b = (bf16)hv;
+    gq.b = (bf16)gv;
+    lut[i] = ((unsigned)gq.s << 16) | (unsigned)h.s;
 }
 
 template <int EPI>
@@ -1342,9 +1391,14 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     if (mode == SC_GEMM_TN) {
         return launch_tn(g, nblocks, st);
     }
+    // GELU by table: only the non-persistent kernel has LDS to spare for it (the persistent one fills all 160 KiB)
+    if (epi == SC_EPI_GELU_GRAD_PAIR) {
+        const char* sw = getenv("SC_GELU_LUT");                  // read per call: A/B switch
+        if (!(sw && sw[0] == '0')) g.gelu_lut = sc_gelu_lut_device(st);
+    }
     // persistent walk of the tile list for the store-only bf16 epilogues once there is more than one round of tiles
     static const bool persist = !(getenv("SC_GEMM_PERSIST") && getenv("SC_GEMM_PERSIST")[0] == '0');
-    if (persist && splitk == 1 && nblocks >= 1024 && ktiles >= 3) {      // >= 4 rounds of tiles (measured: +7 % at 7 rounds, -3 % at 2.3)
+    if (g.gelu_lut == nullptr && persist && splitk == 1 && nblocks >= 1024 && ktiles >= 3) {      // >= 4 rounds of tiles (measured: +7 % at 7 rounds, -3 % at 2.3)
         if (epi == SC_EPI_BF16) return launch_persistent<SC_EPI_BF16>(g, nblocks, st);
         if (epi == SC_EPI_BF16_BIAS) return launch_persistent<SC_EPI_BF16_BIAS>(g, nblocks, st);
         if (epi == SC_EPI_GELU_PAIR) return launch_persistent<SC_EPI_GELU_PAIR>(g, nblocks, st);      // +1.5 % at 9.2 rounds
@@ -1364,4 +1418,26 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     SC_CASE(SC_EPI_BF16_MUL_AUX)
 #undef SC_CASE
     return rc;
+}
+
+// device copy of the GELU table, one per device, filled on first use by the formula itself (sc_gemm_common.h)
+const unsigned* sc_gelu_lut_device(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<int, unsigned*> all;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = all.find(dev);
+    if (it != all.end()) return it->second;
+    unsigned* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), SC_GELU_LUT_N * sizeof(unsigned)) != hipSuccess) p = nullptr;
+    if (p) {
+        sc_gelu_lut_fill_kernel<<<(SC_GELU_LUT_N + 255) / 256, 256, 0, st>>>(p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {     // once per device: later launches may use any stream
+            (void)hipFree(p);
+            p = nullptr;
+        }
+    }
+    all[dev] = p;
+    return p;
 }

@@ -42,7 +42,20 @@ struct GemmArgs {
     const float* q8_scale = nullptr;
     float* q8_amax = nullptr;
     int a_scale_scalar = 0;
+    // GELU-pair epilogues of gemm8p_kernel: table of (gelu'(u) << 16 | gelu(u)) bf16 pairs indexed by the bf16 bits of u (below)
+    const unsigned* gelu_lut = nullptr;
 };
+
+// ---- GELU by table (round 4) ----
+// The GELU epilogues evaluate gelu / gelu' of u AFTER u has been rounded to bf16, and store bf16: both are functions of 16 bits.
+// A table indexed by those bits therefore returns exactly what the formula returns -- it is filled BY the formula
+// (sc_gelu_lut_fill_kernel) -- at ~8 VALU + one LDS read per element instead of ~22 VALU + v_rcp + v_exp.  The table covers
+// 2^-20 <= |u| < 32 (25 binades x 128 mantissas x 2 signs = 6400 entries, 25 KiB of LDS: the operand ring is dead by the time
+// the non-persistent kernel's epilogue runs); a chunk with any value outside (zeros, |u| >= 32: rare) takes the formula.
+constexpr int SC_GELU_LUT_LO = 107 << 7;                // bf16 bits of 2^-20
+constexpr int SC_GELU_LUT_HALF = 25 * 128;              // entries per sign
+constexpr int SC_GELU_LUT_N = 2 * SC_GELU_LUT_HALF;
+const unsigned* sc_gelu_lut_device(hipStream_t st);     // sc_gemm8p.hip: the device copy (built on first use per device), or null
 
 constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes and reads)
 

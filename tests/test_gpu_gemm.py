@@ -94,6 +94,52 @@ def test_nt_persistent_tile_walk_exact(K):
         torch.testing.assert_close(h.float(), gelu(u_ref.float()).to(torch.bfloat16).float(), atol=1e-2, rtol=1e-2)
 
 
+def test_gelu_pair_epilogue_by_table_equals_the_formula_for_every_bf16(monkeypatch):
+    """Round 4: the forward GELU epilogue (C = gelu'(u), C2 = gelu(u), u rounded to bf16 first) reads both values from a 6400-entry
+    LDS table indexed by the bf16 bits of u (2^-20 <= |u| < 32; anything else takes the formula).  The table is filled by the
+    formula, so the two paths must agree bit for bit -- checked here for EVERY finite bf16 value of u (u = a . 1 exactly), with
+    the table on (default) and off (SC_GELU_LUT=0), and against the closed form."""
+    ops = _ops()
+    bits = torch.arange(65536, dtype=torch.int32)
+    vals = bits.to(torch.int16).view(torch.bfloat16)
+    finite = torch.isfinite(vals.float())
+    vals = torch.where(finite, vals, torch.zeros_like(vals))
+    M, N, K = 65536, 256, 64
+    a = torch.zeros((M, K), dtype=torch.bfloat16)
+    a[:, 0] = vals
+    b = torch.zeros((N, K), dtype=torch.bfloat16)
+    b[:, 0] = 1.0
+    bias = torch.zeros(N)
+    outs = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("SC_GELU_LUT", sw)
+        gd = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+        h = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(ops.NT, ops.EPI_GELU_GRAD_PAIR, a.cuda(), b.cuda(), gd, M=M, N=N, K=K, bias=bias.cuda(), out2=h)
+        outs[sw] = (gd.view(torch.int16).cpu(), h.view(torch.int16).cpu())
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    u = vals.float()
+    h = outs["1"][1].view(torch.bfloat16).float()[:, 7]
+    sane = u.abs() < 1e30                              # beyond that the fp32 pieces of the formula overflow (same bits on both paths)
+    torch.testing.assert_close(h[sane], gelu(u)[sane], atol=4e-3, rtol=8e-3)
+    # a tile that mixes in-table and out-of-table values in one 8-element chunk / one wave: the per-chunk fallback
+    monkeypatch.setenv("SC_GELU_LUT", "1")
+    g = torch.Generator().manual_seed(2)
+    M2 = 1024
+    a2 = _rand((M2, K), g)
+    a2[::37, :] = 0                                    # exact zeros (outside the table)
+    a2[5::91, 0] = 300.0                               # |u| far beyond 32
+    b2 = _rand((N, K), g, 0.3)
+    res = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("SC_GELU_LUT", sw)
+        gd = torch.empty((M2, N), dtype=torch.bfloat16, device="cuda")
+        h2 = torch.empty((M2, N), dtype=torch.bfloat16, device="cuda")
+        ops.gemm(ops.NT, ops.EPI_GELU_GRAD_PAIR, a2.cuda(), b2.cuda(), gd, M=M2, N=N, K=K, bias=bias.cuda(), out2=h2)
+        res[sw] = (gd.clone(), h2.clone())
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+
+
 def test_nt_phase_interleaved_splitk_exact():
     ops = _ops()
     M, N, K = 512, 512, 64 * 13
