@@ -1234,7 +1234,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_f8_kernel(const GemmArgs g) {
             for (int j = 0; j < 4; ++j) acc[i][j] *= sb[j] * sa;
         }
     }
-    if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || sc_epi_gelu_fwd(EPI)) {
+    if (EPI == SC_EPI_GELU_GRAD_PAIR && g.gelu_lut != nullptr) {     // GELU by table, as in gemm8p_kernel
+        unsigned* lut = reinterpret_cast<unsigned*>(smem + 8 * 4096);
+        for (int c = t; c < SC_GELU_LUT_N / 4; c += 512)
+            reinterpret_cast<u32x4*>(lut)[c] = reinterpret_cast<const u32x4*>(g.gelu_lut)[c];
+        __syncthreads();
+        epilogue_bf16_lds<EPI, true, true>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane, lut);
+    } else if (EPI == SC_EPI_BF16 || EPI == SC_EPI_BF16_BIAS || sc_epi_gelu_fwd(EPI)) {
         epilogue_bf16_lds<EPI, true>(acc, g, smem + wave * 4096, m0 + wr * 128, n0 + wc * 64, lane);
     } else {
         const int mw = wr * 128;
@@ -1283,6 +1289,10 @@ int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st) {
     g.k_per_split = g.K;
     g.slab_stride = 0;
     const int nblocks = g.ntm * g.ntn;
+    if (epi == SC_EPI_GELU_GRAD_PAIR) {
+        const char* sw = getenv("SC_GELU_LUT");
+        if (!(sw && sw[0] == '0')) g.gelu_lut = sc_gelu_lut_device(st);
+    }
     if (epi == SC_EPI_BF16) return launch_f8<SC_EPI_BF16>(g, nblocks, st);
     if (epi == SC_EPI_BF16_BIAS) return launch_f8<SC_EPI_BF16_BIAS>(g, nblocks, st);
     if (epi == SC_EPI_F32_BIAS_RES) return launch_f8<SC_EPI_F32_BIAS_RES>(g, nblocks, st);

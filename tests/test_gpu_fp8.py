@@ -456,3 +456,29 @@ def test_e4m3_mlp_weight_gradients_in_the_model(monkeypatch):
     for k in mlp_full:
         e = float((grads["w8"][k] - p[k].grad).abs().max() / p[k].grad.abs().max())
         assert e < 0.35, (k, e)
+
+
+def test_fp8_gelu_grad_pair_epilogue_by_table_same_bits(monkeypatch):
+    """The e4m3 NT kernel's forward GELU epilogue (gelu'(u) | gelu(u) | e4m3(gelu(u)) + maxima) reads gelu / gelu' from the same LDS
+    table as the bf16 kernel (filled by the formula; tests/test_gpu_gemm.py checks it for every bf16 value): every output is
+    bit-identical with the table on and off."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 197 * 5 + 3, 1024, 256
+    a = torch.randn(M, K, generator=g)
+    a[::17] = 0                                         # rows of exact zeros: outside the table, per-chunk fallback
+    b = torch.randn(N, K, generator=g) * K ** -0.5
+    bias = torch.zeros(N)
+    a8, sa = ops.quantize_rows_fp8(a.cuda())
+    b8, sb = ops.quantize_rows_fp8(b.cuda())
+    res = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("SC_GELU_LUT", sw)
+        gd = torch.empty((M, N), dtype=torch.bfloat16, device="cuda"); h = torch.empty_like(gd)
+        h8 = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+        amax = torch.zeros(64, device="cuda")
+        ops.gemm_fp8(ops.EPI_GELU_GRAD_PAIR, a8, sa, b8, sb, gd, M=M, N=N, K=K, bias=bias.cuda(), out2=h,
+                     q8_out=h8, q8_scale=torch.full((1,), 16.0, device="cuda"), q8_amax=amax)
+        res[sw] = (gd.clone(), h.clone(), h8.clone(), amax.clone())
+    for x, y in zip(res["1"], res["0"]):
+        assert torch.equal(x, y)
