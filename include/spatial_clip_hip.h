@@ -44,11 +44,15 @@ int sc_abi_version(void);
  *                        h = gelu(u) from the saved u)
  *   SC_EPI_BF16_MUL_AUX  C(bf16) = acc * aux[M,N](bf16)                 (c_proj dgrad x the stored gelu'(u): dU = dH . g;
  *                        SC_EPI_BF16_DGELU rounds its recomputed factor to bf16 first, so both give the same bits)
+ *   SC_EPI_QGELU_PAIR / SC_EPI_BF16_DQGELU / SC_EPI_QGELU_GRAD_PAIR  (round 5) the three GELU epilogues with QuickGELU
+ *                        x * sigmoid(1.702 x) and its derivative in place of the erf GELU: the activation of the
+ *                        OpenAI-pretrained towers (`quick_gelu: true`, src/open_clip/transformer.py:32-35,
+ *                        src/open_clip/model.py:142-145,228, model_configs/ViT-B-16-quickgelu.json).  Same kernels.
  * N % 8 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.  Outer-dimension edges are handled. */
 enum { SC_GEMM_NT = 0, SC_GEMM_TN = 1 };
 enum { SC_EPI_BF16 = 0, SC_EPI_BF16_BIAS = 1, SC_EPI_F32_BIAS_RES = 2, SC_EPI_GELU_PAIR = 3,
        SC_EPI_BF16_DGELU = 4, SC_EPI_F32 = 5, SC_EPI_BF16_BIAS_RES = 6, SC_EPI_GELU_GRAD_PAIR = 7,
-       SC_EPI_BF16_MUL_AUX = 8 };
+       SC_EPI_BF16_MUL_AUX = 8, SC_EPI_QGELU_PAIR = 9, SC_EPI_BF16_DQGELU = 10, SC_EPI_QGELU_GRAD_PAIR = 11 };
 int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                  void* C, int ldc, void* C2, int ldc2, const float* bias, const void* res, int ldres,
                  const void* aux, int ldaux, int splitk, float* slabs, void* stream);
@@ -329,6 +333,9 @@ int sc_augment_tiles(const void* src_u8_hwc, int B, int H, int W, const float* p
  * epilogue's second output).  Used by the activation-recomputation mode (open_clip's CLIP.set_grad_checkpointing,
  * src/open_clip/model.py:313-315): the block's GELU output is not kept for the backward.  n % 8 == 0. */
 int sc_gelu_bf16(const void* u, void* h, long long n, void* stream);
+/* The same pass for towers built with `quick_gelu: true`: h = u * sigmoid(1.702 u) (src/open_clip/transformer.py:32-35),
+ * bit-identical to the second output of SC_EPI_QGELU_PAIR. */
+int sc_quick_gelu_bf16(const void* u, void* h, long long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ RCCL
  * The collectives of the data-parallel step on a caller-supplied HIP stream (enqueue only, never a host wait); RCCL is

@@ -37,6 +37,55 @@ def _force() -> bool:
     return os.environ.get("SC_FORCE_DIST", "0") == "1"
 
 
+# Per-process collective counters (data path only): kind -> [launches, payload bytes this rank contributes / receives].
+# bench.py resets them before the timed steps and prints per-step figures on rank 0, so that a multi-GPU run shows on its
+# own stderr what travelled over xGMI and by which route.
+STATS = {}
+
+
+def _count(kind: str, nbytes: int) -> None:
+    c = STATS.setdefault(kind, [0, 0])
+    c[0] += 1
+    c[1] += int(nbytes)
+
+
+def reset_stats() -> None:
+    STATS.clear()
+
+
+def route() -> str:
+    """Which code enqueues the data-path collectives: 'native' (the kernel library's own RCCL calls on explicit HIP streams,
+    SC_COMM_NATIVE=1) or 'torch.distributed' (ProcessGroupNCCL = RCCL on ROCm, or gloo in the CPU / shared-GPU rehearsals)."""
+    return "native" if _native is not None else "torch.distributed"
+
+
+def describe() -> dict:
+    """Facts about the live group for the bench's stderr / JSON line: backend, ranks the RCCL communicator spans (0 = no RCCL
+    communicator exists: plain single-process run or gloo), RCCL version, route, gradient-exchange mode."""
+    info = {"backend": None, "world_size": 1, "rccl_ranks": 0, "rccl_version": None, "route": route(),
+            "grad_exchange": grad_exchange_mode()}
+    if dist.is_available() and dist.is_initialized():
+        info["backend"] = dist.get_backend()
+        info["world_size"] = dist.get_world_size()
+        if info["backend"] == "nccl":
+            # a SUM all-reduce of ones over the communicator the step uses: the number of ranks RCCL itself reaches
+            t = torch.ones(1, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            info["rccl_ranks"] = int(round(float(t.cpu()[0])))
+            try:
+                info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                info["rccl_version"] = "unknown"
+    return info
+
+
+def grad_exchange_mode() -> str:
+    """SC_GRAD_EXCHANGE = 'sharded' (default: per-bucket reduce-scatter -> AdamW on this rank's 1/W of every bucket ->
+    all-gather of the refreshed weights) or 'allreduce' (rounds 1-4: bucketed SUM all-reduce of the flat
+    gradient, AdamW replicated on every rank).  Same weights either way (tests/test_gpu_ddp.py)."""
+    return os.environ.get("SC_GRAD_EXCHANGE", "sharded")
+
+
 def is_dist() -> bool:
     if not (dist.is_available() and dist.is_initialized()):
         return False
@@ -243,6 +292,7 @@ def gather_packed(image_features: torch.Tensor, text_features: torch.Tensor,
         packed[:, 2 * D:2 * D + 2].view(torch.int64).copy_(image_tile_ids.view(B, 1))
         packed[:, 2 * D + 2:2 * D + 4].view(torch.int64).copy_(text_tile_ids.view(B, 1))
     out = torch.empty((W * B, cols), dtype=torch.float32, device=packed.device)
+    _count("all_gather(features|ids)", out.numel() * 4)
     if _native is not None and packed.is_cuda:
         _native.all_gather(packed, out, torch.cuda.current_stream(packed.device))
     else:
@@ -299,6 +349,7 @@ class FeatureGather:
         send = self._buf(self._send, which, (B, cols))
         recv = self._buf(self._recv, which, (W * B, cols))
         self._src[which] = (feat.data_ptr(), D, ids_i is not None)
+        _count("all_gather(features|ids)", recv.numel() * 4)
         if not self.cuda:
             _pack(feat, ids_i, ids_t, send)
             dist.all_gather_into_tensor(recv, send)
@@ -349,6 +400,7 @@ def reduce_scatter_sum(full: torch.Tensor) -> torch.Tensor:
     rank, W = world()
     B = full.shape[0] // W
     full = full.contiguous()
+    _count("reduce_scatter(d features)", full.numel() * full.element_size())
     if dist.get_backend() == "gloo":          # gloo has no reduce_scatter: all-reduce and slice
         dist.all_reduce(full, op=dist.ReduceOp.SUM)
         return full[rank * B:(rank + 1) * B].clone()
@@ -391,6 +443,7 @@ class GradBucketReducer:
 
     def _reduce(self, lo: int, hi: int):
         """Enqueue the SUM all-reduce of flat[lo:hi] behind the caller's stream; returns what finish() waits on."""
+        _count("all_reduce(gradient bucket)", (hi - lo) * 4)
         if _native is not None and self.flat.is_cuda:
             cur = torch.cuda.current_stream(self.flat.device)
             ready = torch.cuda.Event()

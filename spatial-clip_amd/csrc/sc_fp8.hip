@@ -150,6 +150,8 @@ static int gemm_fp8_impl(int epi, const void* A8, int lda, const float* a_scale_
                          const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2,
                          const float* bias, const void* res, int ldres, const void* aux, int ldaux, void* q8_out,
                          long long ldq8, const float* q8_scale, float* q8_amax, void* stream) {
+    const int act = sc_epi_act(epi);          // SC_EPI_QGELU_*: the erf twin's kernel instance with the activation flag set
+    epi = sc_epi_base(epi);
     SC_CHECK(M > 0 && N > 0 && K > 0 && (K % 128) == 0, "sc_gemm_fp8: K (%d) must be a positive multiple of 128", K);
     SC_CHECK((lda % 16) == 0 && (ldb % 16) == 0 && ((uintptr_t)A8 % 16) == 0 && ((uintptr_t)B8 % 16) == 0,
              "sc_gemm_fp8: operand rows must be 16-byte aligned (lda=%d ldb=%d)", lda, ldb);
@@ -161,6 +163,7 @@ static int gemm_fp8_impl(int epi, const void* A8, int lda, const float* a_scale_
     g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = (const float*)res; g.ldres = ldres;
     g.aux = (const bf16*)aux; g.ldaux = ldaux; g.colsum = nullptr; g.tile_offset = 0;
     g.a_scale = a_scale_inv; g.b_scale = b_scale_inv; g.a_scale_scalar = a_scale_scalar;
+    g.act = act;
     if (q8_out != nullptr) {
         SC_CHECK(sc_epi_gelu_fwd(epi) || sc_epi_aux_mul(epi), "sc_gemm_fp8_q: the e4m3 second output exists for the GELU pair / GELU' epilogues");
         SC_CHECK(q8_scale != nullptr && q8_amax != nullptr && ldq8 >= N && (ldq8 % 8) == 0 && ((uintptr_t)q8_out % 8) == 0,

@@ -248,6 +248,8 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
                             void* C, int ldc, void* C2, int ldc2, const float* bias, const void* res, int ldres,
                             const void* aux, int ldaux, int splitk, float* slabs, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    const int act = sc_epi_act(epi);          // SC_EPI_QGELU_*: the erf twin's kernel instance with the activation flag set
+    epi = sc_epi_base(epi);
     SC_CHECK(mode == SC_GEMM_NT || mode == SC_GEMM_TN, "sc_gemm_bf16: bad mode %d", mode);
     SC_CHECK(M > 0 && N > 0 && K > 0, "sc_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
     const bool f32out = (epi == SC_EPI_F32 || epi == SC_EPI_F32_BIAS_RES);
@@ -266,6 +268,7 @@ extern "C" int sc_gemm_bf16(int mode, int epi, const void* A, int lda, const voi
     g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = (const float*)res; g.ldres = ldres;
     g.aux = (const bf16*)aux; g.ldaux = ldaux;
     g.colsum = nullptr; g.tile_offset = 0;
+    g.act = act;
     // kernel choice: 256x256 phase-interleaved kernel (NT) -> 256x256 two-stage LDS-DMA kernel (TN, and NT when
     // pinned) -> 128x128 general kernel.  SC_GEMM_FORCE = 128 | 256 pins one kernel for A/B benchmarking.
     static const char* force = getenv("SC_GEMM_FORCE");

@@ -92,7 +92,7 @@ SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* st
                     bf16x8 o;
                     if (EPI == SC_EPI_GELU_PAIR) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_gelu_fast((float)x.h[e]);
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_act((float)x.h[e], g.act);
                     } else {                             // the backward's factor gelu'(u) instead of u
                         bf16x8 gd;
                         bool formula = true;
@@ -123,7 +123,7 @@ SC_DEVICE void epilogue_bf16_lds(f32x4 (&acc)[8][4], const GemmArgs& g, char* st
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 float hv, gv;
-                                sc_gelu_both((float)x.h[e], hv, gv);
+                                sc_act_both((float)x.h[e], g.act, hv, gv);
                                 o[e] = (bf16)hv;
                                 gd[e] = (bf16)gv;
                             }
@@ -326,13 +326,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
     }
 }
 
-__global__ void sc_gelu_lut_fill_kernel(unsigned* lut) {
+__global__ void sc_gelu_lut_fill_kernel(unsigned* lut, int act) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= SC_GELU_LUT_N) return;
     const unsigned bits = (unsigned)(SC_GELU_LUT_LO + i % SC_GELU_LUT_HALF) | (i >= SC_GELU_LUT_HALF ? 0x8000u : 0u);
     const float u = __uint_as_float(bits << 16);
     float hv, gv;
-    sc_gelu_both(u, hv, gv);
+    sc_act_both(u, act, hv, gv);
     union { bf16 b; unsigned short s; } h, gq;
     h.b = (bf16)hv;
     gq.b = (bf16)gv;
@@ -1291,7 +1291,7 @@ int sc_gemm8p_fp8(int epi, GemmArgs& g, hipStream_t st) {
     const int nblocks = g.ntm * g.ntn;
     if (epi == SC_EPI_GELU_GRAD_PAIR) {
         const char* sw = getenv("SC_GELU_LUT");
-        if (!(sw && sw[0] == '0')) g.gelu_lut = sc_gelu_lut_device(st);
+        if (!(sw && sw[0] == '0')) g.gelu_lut = sc_gelu_lut_device(st, g.act);
     }
     if (epi == SC_EPI_BF16) return launch_f8<SC_EPI_BF16>(g, nblocks, st);
     if (epi == SC_EPI_BF16_BIAS) return launch_f8<SC_EPI_BF16_BIAS>(g, nblocks, st);
@@ -1404,7 +1404,7 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     // GELU by table: only the non-persistent kernel has LDS to spare for it (the persistent one fills all 160 KiB)
     if (epi == SC_EPI_GELU_GRAD_PAIR) {
         const char* sw = getenv("SC_GELU_LUT");                  // read per call: A/B switch
-        if (!(sw && sw[0] == '0')) g.gelu_lut = sc_gelu_lut_device(st);
+        if (!(sw && sw[0] == '0')) g.gelu_lut = sc_gelu_lut_device(st, g.act);
     }
     // persistent walk of the tile list for the store-only bf16 epilogues once there is more than one round of tiles
     static const bool persist = !(getenv("SC_GEMM_PERSIST") && getenv("SC_GEMM_PERSIST")[0] == '0');
@@ -1430,24 +1430,25 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     return rc;
 }
 
-// device copy of the GELU table, one per device, filled on first use by the formula itself (sc_gemm_common.h)
-const unsigned* sc_gelu_lut_device(hipStream_t st) {
+// device copy of the GELU table, one per device and activation, filled on first use by the formula itself (sc_gemm_common.h)
+const unsigned* sc_gelu_lut_device(hipStream_t st, int act) {
     static std::mutex mu;
     static std::map<int, unsigned*> all;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const int key = dev * 2 + (act ? 1 : 0);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = all.find(dev);
+    auto it = all.find(key);
     if (it != all.end()) return it->second;
     unsigned* p = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&p), SC_GELU_LUT_N * sizeof(unsigned)) != hipSuccess) p = nullptr;
     if (p) {
-        sc_gelu_lut_fill_kernel<<<(SC_GELU_LUT_N + 255) / 256, 256, 0, st>>>(p);
+        sc_gelu_lut_fill_kernel<<<(SC_GELU_LUT_N + 255) / 256, 256, 0, st>>>(p, act ? 1 : 0);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {     // once per device: later launches may use any stream
             (void)hipFree(p);
             p = nullptr;
         }
     }
-    all[dev] = p;
+    all[key] = p;
     return p;
 }

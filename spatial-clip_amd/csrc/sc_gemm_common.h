@@ -44,6 +44,9 @@ struct GemmArgs {
     int a_scale_scalar = 0;
     // GELU-pair epilogues of gemm8p_kernel: table of (gelu'(u) << 16 | gelu(u)) bf16 pairs indexed by the bf16 bits of u (below)
     const unsigned* gelu_lut = nullptr;
+    // activation of the GELU epilogues: 0 = exact-erf GELU (nn.GELU), 1 = QuickGELU x * sigmoid(1.702 x) (the ABI's
+    // SC_EPI_QGELU_* values select the same template instance with act = 1; wave-uniform, so the choice is a scalar branch)
+    int act = 0;
 };
 
 // ---- GELU by table (round 4) ----
@@ -55,7 +58,7 @@ struct GemmArgs {
 constexpr int SC_GELU_LUT_LO = 107 << 7;                // bf16 bits of 2^-20
 constexpr int SC_GELU_LUT_HALF = 25 * 128;              // entries per sign
 constexpr int SC_GELU_LUT_N = 2 * SC_GELU_LUT_HALF;
-const unsigned* sc_gelu_lut_device(hipStream_t st);     // sc_gemm8p.hip: the device copy (built on first use per device), or null
+const unsigned* sc_gelu_lut_device(hipStream_t st, int act = 0);     // sc_gemm8p.hip: the device copy (built on first use per device and activation), or null
 
 constexpr int SC_EPI_LD = 68;  // floats per staged epilogue row (64 + 4 pad: conflict-free b128 writes and reads)
 
@@ -102,6 +105,33 @@ SC_DEVICE void sc_gelu_both(float x, float& h, float& g) {
 // from the bf16 tensor the forward epilogue stored (SC_EPI_BF16_MUL_AUX) -- recomputation mode must give the same bits
 SC_DEVICE float sc_gelu_grad_bf16(float x) { return (float)(bf16)sc_gelu_grad_fast(x); }
 
+// ---- QuickGELU (the OpenAI-pretrained towers: src/open_clip/transformer.py:32-35, model.py:142-145 act_layer = QuickGELU) ----
+//   s = sigmoid(1.702 x) = 1 / (1 + 2^(-1.702 log2(e) x));  h = x s;  h' = s + 1.702 x s (1 - s) = s + [1.702 (1 - s)] h
+// (in this order no intermediate overflows for any finite x: s -> 0 or 1 exactly at the ends, and 0 * h stays 0)
+SC_DEVICE void sc_qgelu_both(float x, float& h, float& g) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
+    h = x * s;
+    g = __builtin_fmaf(1.702f * (1.0f - s), h, s);
+}
+// activation-generic forms used by every epilogue: act is a kernel argument (wave-uniform)
+SC_DEVICE float sc_act(float x, int act) {
+    if (act) { float h, g; sc_qgelu_both(x, h, g); return h; }
+    return sc_gelu_fast(x);
+}
+SC_DEVICE void sc_act_both(float x, int act, float& h, float& g) {
+    if (act) sc_qgelu_both(x, h, g); else sc_gelu_both(x, h, g);
+}
+SC_DEVICE float sc_act_grad_bf16(float x, int act) {
+    if (act) { float h, g; sc_qgelu_both(x, h, g); return (float)(bf16)g; }
+    return sc_gelu_grad_bf16(x);
+}
+
+// ABI epilogue values 9..11 = the GELU epilogues with QuickGELU: same kernels, GemmArgs::act = 1
+constexpr int sc_epi_act(int e) { return (e == SC_EPI_QGELU_PAIR || e == SC_EPI_BF16_DQGELU || e == SC_EPI_QGELU_GRAD_PAIR) ? 1 : 0; }
+constexpr int sc_epi_base(int e) {
+    return e == SC_EPI_QGELU_PAIR ? SC_EPI_GELU_PAIR : e == SC_EPI_BF16_DQGELU ? SC_EPI_BF16_DGELU
+         : e == SC_EPI_QGELU_GRAD_PAIR ? SC_EPI_GELU_GRAD_PAIR : e;
+}
 constexpr bool sc_epi_gelu_fwd(int e) { return e == SC_EPI_GELU_PAIR || e == SC_EPI_GELU_GRAD_PAIR; }   // two bf16 outputs
 constexpr bool sc_epi_aux_mul(int e) { return e == SC_EPI_BF16_DGELU || e == SC_EPI_BF16_MUL_AUX; }      // bf16 input tile, product
 
@@ -226,7 +256,7 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
             if (sc_epi_aux_mul(EPI)) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k)          // aux = the pre-GELU tensor u (DGELU) or the stored factor gelu'(u) (MUL_AUX)
-                    v[k] *= (EPI == SC_EPI_BF16_DGELU) ? sc_gelu_grad_bf16((float)e.a[ps][k]) : (float)e.a[ps][k];
+                    v[k] *= (EPI == SC_EPI_BF16_DGELU) ? sc_act_grad_bf16((float)e.a[ps][k], g.act) : (float)e.a[ps][k];
                 if (next_gm0 >= 0) {
                     const int gm2 = next_gm0 + row;
                     if (gm2 < g.M && gn < g.N)
@@ -259,7 +289,7 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
                 if (EPI == SC_EPI_GELU_PAIR) {
                     bf16x8 h;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) h[k] = (bf16)sc_gelu_fast((float)o[k]);
+                    for (int k = 0; k < 8; ++k) h[k] = (bf16)sc_act((float)o[k], g.act);
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(g.C2) + (size_t)gm * g.ldc2 + gn) = h;
                 }
                 if (EPI == SC_EPI_GELU_GRAD_PAIR) {          // C = gelu'(u), C2 = gelu(u), u = bf16(acc + bias) never stored
@@ -267,7 +297,7 @@ SC_DEVICE void sc_epilogue_store(const float* ep, EpiRegs<EPI>& e, int gm0, int 
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         float hv, gv;
-                        sc_gelu_both((float)o[k], hv, gv);
+                        sc_act_both((float)o[k], g.act, hv, gv);
                         h[k] = (bf16)hv;
                         gd[k] = (bf16)gv;
                     }

@@ -319,12 +319,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 // The activation-recomputation mode (SpatialClipNet.set_grad_checkpointing) does not keep the GELU output of a block for
 // the backward; the c_proj weight gradient gets it back from the saved pre-activation u with the epilogue's own formula
 // on the epilogue's own input (the bf16-rounded u), i.e. bit-identical to what the forward wrote.
-__global__ __launch_bounds__(256) void gelu_bf16_kernel(const bf16* __restrict__ u, bf16* __restrict__ h, long long n8) {
+__global__ __launch_bounds__(256) void gelu_bf16_kernel(const bf16* __restrict__ u, bf16* __restrict__ h, long long n8, int act) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(u + i * 8);
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_gelu_fast((float)v[e]);
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)sc_act((float)v[e], act);
         *reinterpret_cast<bf16x8*>(h + i * 8) = o;
     }
 }
@@ -765,12 +765,16 @@ extern "C" int sc_cast_transpose_bf16(const float* src, void* dst, int rows, int
     return 0;
 }
 
-extern "C" int sc_gelu_bf16(const void* u, void* h, long long n, void* stream) {
+static int act_bf16_impl(const void* u, void* h, long long n, int act, void* stream) {
     SC_CHECK(n > 0 && (n % 8) == 0, "sc_gelu_bf16: element count must be a positive multiple of 8 (n=%lld)", n);
     const long long n8 = n / 8;
     long long blocks = (n8 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    gelu_bf16_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const bf16*)u, (bf16*)h, n8);
+    gelu_bf16_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const bf16*)u, (bf16*)h, n8, act);
     SC_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int sc_gelu_bf16(const void* u, void* h, long long n, void* stream) { return act_bf16_impl(u, h, n, 0, stream); }
+
+extern "C" int sc_quick_gelu_bf16(const void* u, void* h, long long n, void* stream) { return act_bf16_impl(u, h, n, 1, stream); }

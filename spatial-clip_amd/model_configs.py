@@ -74,6 +74,10 @@ class ModelCfg:
     text: Optional[TextCfg] = None
     gene: Optional[GeneCfg] = None
     init_logit_scale: float = math.log(1 / 0.07)     # src/open_clip/model.py:273
+    # `quick_gelu: true` of the *-quickgelu model configs: act_layer = QuickGELU in BOTH reference towers
+    # (src/open_clip/model.py:142-145,228; the OpenAI-pretrained weights were trained with it).  The gene towers are this
+    # build's own definition and keep the exact-erf GELU.
+    quick_gelu: bool = False
 
 
 def _clip(embed, v_layers, v_width, patch, t_width, t_heads, t_layers=12, image=224) -> ModelCfg:
@@ -89,6 +93,10 @@ _REGISTRY: Dict[str, ModelCfg] = {
     "ViT-S-32": _clip(384, 12, 384, 32, 384, 6),
     "ViT-Ti-16": _clip(512, 12, 192, 16, 256, 4),
 }
+# src/open_clip/model_configs/ViT-B-16-quickgelu.json, ViT-B-32-quickgelu.json, ViT-L-14-quickgelu.json: the same
+# architectures with `"quick_gelu": true`
+for _base in ("ViT-B-16", "ViT-B-32", "ViT-L-14"):
+    _REGISTRY[_base + "-quickgelu"] = replace(_REGISTRY[_base], quick_gelu=True)
 
 
 def get_model_config(model_name: str, n_genes: Optional[int] = None, gene_hidden: Optional[int] = None) -> ModelCfg:
@@ -106,7 +114,7 @@ def get_model_config(model_name: str, n_genes: Optional[int] = None, gene_hidden
         raise RuntimeError(f"Model config for {model_name} not found. Available: {sorted(list_models())}")
     cfg = _REGISTRY[name]
     cfg = ModelCfg(cfg.embed_dim, replace(cfg.vision), replace(cfg.text) if cfg.text else None, None,
-                   cfg.init_logit_scale)
+                   cfg.init_logit_scale, cfg.quick_gelu)
     if gene:
         cfg.text = None
         cfg.gene = GeneCfg(n_genes or 20000, gene_hidden or 512, kind=kind)

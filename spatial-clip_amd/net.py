@@ -82,6 +82,49 @@ def resize_pos_embed(state_dict: Dict[str, torch.Tensor], grid_size, interpolati
     state_dict["visual.positional_embedding"] = torch.cat([tok.float(), img], dim=0).to(old.dtype)
 
 
+def resize_text_pos_embed(state_dict: Dict[str, torch.Tensor], num_pos: int, interpolation: str = "linear",
+                          antialias: bool = False) -> None:
+    """Resample the text tower's positional embedding of a checkpoint to this model's context length when they differ
+    (``src/open_clip/model.py:826-860``, called from ``load_checkpoint`` right after ``resize_pos_embed``,
+    factory.py:220-221): 1-D linear interpolation along the position axis, ``align_corners=False``, width unchanged.
+    In place on ``state_dict['positional_embedding']`` (or ``'text.positional_embedding'``, the custom-text layout)."""
+    key = "positional_embedding" if "positional_embedding" in state_dict else "text.positional_embedding"
+    old = state_dict.get(key)
+    if old is None:
+        return
+    old_num, width = old.shape
+    if old_num == int(num_pos):
+        return
+    x = old.float().reshape(1, old_num, width).permute(0, 2, 1)
+    x = torch.nn.functional.interpolate(x, size=int(num_pos), mode=interpolation, antialias=antialias, align_corners=False)
+    state_dict[key] = x.permute(0, 2, 1)[0].to(old.dtype)
+
+
+def read_checkpoint_file(path: str) -> Dict[str, Any]:
+    """What ``open_clip.factory.load_state_dict`` accepts (src/open_clip/factory.py:153-178): a ``.safetensors`` file
+    (``safetensors.torch.load_file``), a pickled state_dict / training checkpoint (``{'state_dict': ...}``), or a TorchScript
+    archive (OpenAI's released ``.pt`` files: ``state_dict()`` minus the three bookkeeping buffers).  Host tensors."""
+    if str(path).endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path, device="cpu")
+    try:
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as first:
+        try:        # TorchScript archives are zip files torch.load(weights_only=True) refuses; torch.jit.load reads them
+            ckpt = torch.jit.load(path, map_location="cpu")
+        except Exception:
+            try:    # checkpoints that pickle more than tensors (Lightning: hyper-parameters, callbacks)
+                ckpt = torch.load(path, map_location="cpu", weights_only=False)
+            except Exception:
+                raise first
+    if isinstance(ckpt, torch.jit.ScriptModule):
+        sd = dict(ckpt.state_dict())
+        for k in ("input_resolution", "context_length", "vocab_size"):
+            sd.pop(k, None)
+        return sd
+    return ckpt
+
+
 _CKPT_PREFIXES = ("net.model.", "model.", "module.", "net.")
 
 
@@ -113,12 +156,14 @@ class _ClipFacade:
         """CLIP.encode_image (src/open_clip/model.py:326-328), inference only: ``normalize=False`` returns the
         projected features before F.normalize."""
         with torch.no_grad():
+            self._net._mark_pass(False)
             f = self._net.vision.forward(image)
             return (f if normalize else self._net.vision.raw_features()).clone()
 
     def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         """CLIP.encode_text (src/open_clip/model.py:330-345) / the gene tower, inference only."""
         with torch.no_grad():
+            self._net._mark_pass(False)
             f = self._net.second.forward(text)
             return (f if normalize else self._net.second.raw_features()).clone()
 
@@ -205,6 +250,14 @@ class SpatialClipNet(torch.nn.Module):
             out[name] = None if st is None else st["choice"]
         return out
 
+    def side_stream_timing(self) -> Dict[str, Optional[Dict[str, float]]]:
+        """Per transformer stack: the best backward time (ms) ``SC_OVERLAP=auto`` measured on each schedule, or None."""
+        out = {}
+        for name, stack in self._stacks():
+            st = getattr(stack, "_ov_auto", {}).get((getattr(stack, "B", None), getattr(stack, "L", None)))
+            out[name] = None if st is None else st.get("ms_best")
+        return out
+
     def reset_fp8_scaling(self) -> None:
         """fp8 path: drop the per-tensor scales carried from the previous steps (towers.TransformerStack.reset_fp8_scaling)."""
         for _, stack in self._stacks():
@@ -223,8 +276,7 @@ class SpatialClipNet(torch.nn.Module):
 
     def _load_pretrained(self, pretrained: str) -> None:
         if os.path.isfile(pretrained):        # local checkpoint path branch of factory.py:418-421
-            sd = torch.load(pretrained, map_location="cpu")
-            self.load_checkpoint_state_dict(sd, source=pretrained)
+            self.load_checkpoint_state_dict(read_checkpoint_file(pretrained), source=pretrained)
             return
         # tags such as laion2b_s34b_b79k resolve to a hub download in the reference (pretrained.py:843,880-912)
         raise RuntimeError(f"Pretrained weights ({pretrained}) for model {self.model_name} not found: "
@@ -261,6 +313,11 @@ class SpatialClipNet(torch.nn.Module):
         if self.cfg.vision is not None:
             g = self.cfg.vision.image_size // self.cfg.vision.patch_size
             resize_pos_embed(sd, (g, g))
+        if self.cfg.text is not None:           # factory.py:221: the text positions follow the model's context length
+            resize_text_pos_embed(sd, self.cfg.text.context_length)
+        ls = sd.get("logit_scale")              # factory.py:203-204: scalar vs 1-element parameter
+        if ls is not None and ls.ndim != 0 and ls.numel() == 1:
+            sd["logit_scale"] = ls.reshape(())
         matched = {k: v for k, v in sd.items() if k in self.store.by_name}
         missing = [n for n in self.store.by_name if n not in matched]
         unexpected = [k for k in sd if k not in self.store.by_name]
@@ -291,11 +348,17 @@ class SpatialClipNet(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, images: torch.Tensor, texts: torch.Tensor) -> Dict[str, torch.Tensor]:
-        train_pass = torch.is_grad_enabled()        # read HERE: inside autograd.Function.forward grad mode is always off
-        for _, stack in self._stacks():
-            stack.fp8_train_pass = train_pass
+        self._mark_pass(torch.is_grad_enabled())    # read HERE: inside autograd.Function.forward grad mode is always off
         img, txt, s = _NetFn.apply(self.store.params["logit_scale"], self, images, texts)
         return {"image_features": img, "text_features": txt, "logit_scale": s, "logit_bias": None}
+
+    def _mark_pass(self, train_pass: bool) -> None:
+        """Tell the stacks whether the forward about to run will be differentiated.  Only such a pass records e4m3 maxima,
+        consumes the delayed scales or overwrites the per-block e4m3 copies the backward reads; evaluation forwards --
+        SpatialClipNet.forward under no_grad AND every encode_image / encode_text call (the zero-shot bank) -- do none of
+        that, so they give the numbers a fresh process gives for the same weights (advisor, rounds 3-4)."""
+        for _, stack in self._stacks():
+            stack.fp8_train_pass = bool(train_pass)
 
     def _bucket(self, names: List[str]) -> None:
         if self.grad_bucket_hook is not None:

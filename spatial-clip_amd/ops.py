@@ -12,7 +12,15 @@ from ._lib import check
 
 NT, TN = 0, 1
 (EPI_BF16, EPI_BF16_BIAS, EPI_F32_BIAS_RES, EPI_GELU_PAIR, EPI_BF16_DGELU, EPI_F32, EPI_BF16_BIAS_RES, EPI_GELU_GRAD_PAIR,
- EPI_BF16_MUL_AUX) = range(9)
+ EPI_BF16_MUL_AUX, EPI_QGELU_PAIR, EPI_BF16_DQGELU, EPI_QGELU_GRAD_PAIR) = range(12)
+
+
+def act_epilogues(quick_gelu: bool):
+    """(pair, grad_pair, dgelu) epilogues of a block's activation: exact-erf GELU (nn.GELU) or, for towers built with
+    ``quick_gelu: true`` (src/open_clip/model.py:142-145), QuickGELU x * sigmoid(1.702 x)."""
+    if quick_gelu:
+        return EPI_QGELU_PAIR, EPI_QGELU_GRAD_PAIR, EPI_BF16_DQGELU
+    return EPI_GELU_PAIR, EPI_GELU_GRAD_PAIR, EPI_BF16_DGELU
 
 
 def _stream() -> int:
@@ -72,7 +80,12 @@ def gemm(mode: int, epi: int, a: torch.Tensor, b: torch.Tensor, out: torch.Tenso
                         _ptr(aux), aux.stride(0) if aux is not None else 0, splitk, _ptr(slabs), _stream())
     if ev is not None:
         ev[1].record()
-        KERNEL_EVENTS.append(("gemm_nt" if mode == NT else "gemm_tn", 2.0 * M * N * K, ev))
+        # algorithmic bytes of the launch: both operands once, every output once, every epilogue input once
+        ob = 4 if want == torch.float32 else 2
+        nbytes = 2.0 * M * K + 2.0 * N * K + float(ob) * M * N
+        nbytes += (2.0 * M * N if out2 is not None else 0.0) + (float(res.element_size()) * M * N if res is not None else 0.0)
+        nbytes += (2.0 * M * N if aux is not None else 0.0) + (4.0 * N if bias is not None else 0.0)
+        KERNEL_EVENTS.append(("gemm_nt" if mode == NT else "gemm_tn", 2.0 * M * N * K, ev, nbytes))
     check(rc, "sc_gemm_bf16")
     return out
 
@@ -231,12 +244,14 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows: int, d: int, ldx: Optiona
     return y
 
 
-def gelu_bf16(u: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
-    """h = gelu(u) (bf16 -> bf16, contiguous), bit-identical to the GELU-pair GEMM epilogue's second output."""
+def gelu_bf16(u: torch.Tensor, h: torch.Tensor, quick: bool = False) -> torch.Tensor:
+    """h = gelu(u) (bf16 -> bf16, contiguous), bit-identical to the GELU-pair GEMM epilogue's second output; ``quick``:
+    QuickGELU (the SC_EPI_QGELU_PAIR epilogue's)."""
     _req(u, torch.bfloat16, "u"); _req(h, torch.bfloat16, "h")
     if not (u.is_contiguous() and h.is_contiguous()) or u.numel() != h.numel():
         raise ValueError("gelu_bf16: contiguous tensors of equal size required")
-    check(_lib.lib().sc_gelu_bf16(u.data_ptr(), h.data_ptr(), u.numel(), _stream()), "sc_gelu_bf16")
+    fn = _lib.lib().sc_quick_gelu_bf16 if quick else _lib.lib().sc_gelu_bf16
+    check(fn(u.data_ptr(), h.data_ptr(), u.numel(), _stream()), "sc_gelu_bf16")
     return h
 
 

@@ -92,7 +92,7 @@ class TransformerStack:
     """N pre-LN residual attention blocks (ResidualAttentionBlock, transformer.py:238-300)."""
 
     def __init__(self, store: ParamStore, prefix: str, width: int, heads: int, layers: int, mlp: int, causal: bool,
-                 cls_only_last: bool = False, res16_ok: bool = False):
+                 cls_only_last: bool = False, res16_ok: bool = False, quick_gelu: bool = False):
         # cls_only_last: only token 0 of the last block's output is consumed downstream (ViT pool 'tok'), so that
         # block computes K/V for all tokens but attention output, out_proj and the MLP for the CLS rows only -- the
         # values the reference would compute for the other 196 rows are dead.
@@ -101,6 +101,10 @@ class TransformerStack:
         self.d, self.H, self.layers, self.mlp, self.causal = width, heads, layers, mlp, causal
         self.dh = width // heads
         self.bufs = _Bufs(store.device)
+        # act_layer = QuickGELU for towers built from a `quick_gelu: true` config (OpenAI-pretrained weights,
+        # src/open_clip/model.py:142-145,228): the three GELU epilogues with x * sigmoid(1.702 x) and its derivative
+        self.quick_gelu = bool(quick_gelu)
+        self.epi_pair, self.epi_grad_pair, self.epi_dgelu = ops.act_epilogues(self.quick_gelu)
         self.fp8 = bool(getattr(store, "fp8", False))
         # residual stream in bf16 (what the reference's autocast keeps; SC_RES_STREAM, read at every forward) for the towers
         # whose stem / head kernels take it (the patch towers); off: fp32 stream
@@ -118,7 +122,7 @@ class TransformerStack:
         # a forward whose backward will run (grad mode on: set by SpatialClipNet.forward) records maxima and may consume the
         # delayed scales; evaluation forwards (validation, test, zero-shot bank) do neither: they run the h consumer in bf16, so
         # a fresh eval process and an in-fit validation of the same weights give the same numbers (advisor, round 3)
-        self.fp8_train_pass = True
+        self.fp8_train_pass = False     # set per call by SpatialClipNet.forward; encode_image / encode_text never train
         self._dq_step = 0
         # e4m3 weight gradients of the MLP pair (round 4, sc_gemm_wgrad_fp8): their operands need ONE scale per tensor -- h and
         # dU have such copies already (entries 2 i, 2 i + 1); the LayerNorm kernels add per-tensor copies of a2 = ln_2(x) and of
@@ -159,13 +163,16 @@ class TransformerStack:
 
     def load_fp8_scaling_state(self, st: Optional[Dict[str, object]]) -> None:
         self.reset_fp8_scaling()
-        if not self.fp8 or not st or tuple(st["scale"].shape) != tuple(self._dq_scale.shape) \
-                or tuple(st["hist"].shape) != tuple(self._dq_hist.shape):
+        if not self.fp8 or not isinstance(st, dict):
             return
-        self._dq_scale.copy_(st["scale"])
-        self._dq_scale_inv.copy_(st["scale_inv"])
-        self._dq_hist.copy_(st["hist"])
-        self._dq_ready, self._dq_step = bool(st["ready"]), int(st["step"])
+        want = {"scale": self._dq_scale, "scale_inv": self._dq_scale_inv, "hist": self._dq_hist}
+        for k, dst in want.items():          # a malformed / foreign checkpoint entry resets the history instead of raising
+            t = st.get(k)
+            if not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(dst.shape):
+                return
+        for k, dst in want.items():
+            dst.copy_(st[k])
+        self._dq_ready, self._dq_step = bool(st.get("ready", False)), int(st.get("step", 0))
 
     def _act(self, kind: str, i: int, shape) -> torch.Tensor:
         """Buffer of a block's recomputable activation (a1 / a2 / h): one per block, or two rotating ones in
@@ -215,7 +222,7 @@ class TransformerStack:
         # copies of h and a2 are KEPT per block (1 + 0.25 bytes per MLP element instead of the 2 + 0.5 of the bf16 tensors that
         # recomputation drops), and the backward then has nothing to rebuild for the MLP branch
         use_w8 = self._fwd_w8 = bool(self.fp8 and self._dq_on and self._w8_on and self.fp8_train_pass and r16
-                                     and M % 128 == 0 and d % 16 == 0 and mlp % 16 == 0 and d >= 256)
+                                     and M % 128 == 0 and d % 16 == 0 and mlp % 16 == 0 and d >= 256 and mlp >= 256)
         self.x_in = [None] * self.layers
         for i in range(self.layers):
             self.x_in[i] = x
@@ -250,7 +257,7 @@ class TransformerStack:
             # it rebuilds h = gelu(u)
             u = bf.get(f"u.{i}", (M, mlp), BF16)
             h = self._act("h", i, (M, mlp))
-            epi_gelu = ops.EPI_GELU_PAIR if self.recompute else ops.EPI_GELU_GRAD_PAIR
+            epi_gelu = self.epi_pair if self.recompute else self.epi_grad_pair
             self._u_holds_grad = not self.recompute        # what THIS forward left in the u buffers (read by backward)
             hq = None
             if self.fp8 and self._dq_on and self.fp8_train_pass:      # the GELU epilogue also emits e4m3(h) with last step's scale + records max|h|
@@ -285,7 +292,7 @@ class TransformerStack:
         ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
                           bf.get("c.m2", (B,), F32), bf.get("c.r2", (B,), F32), B, d)
         u, h = bf.get("c.u", (B, mlp), BF16), bf.get("c.h", (B, mlp), BF16)
-        ops.gemm(ops.NT, ops.EPI_GELU_GRAD_PAIR, a2, s.copies[self._n(i, "mlp.c_fc.weight")].wf, u, M=B, N=mlp, K=d,
+        ops.gemm(ops.NT, self.epi_grad_pair, a2, s.copies[self._n(i, "mlp.c_fc.weight")].wf, u, M=B, N=mlp, K=d,
                  bias=s.p(self._n(i, "mlp.c_fc.bias")), out2=h)           # "u" holds gelu'(u): this block is never recomputed
         xo = bf.get("c.xout", (B, d), XD)
         ops.gemm(ops.NT, epi_res, h, s.copies[self._n(i, "mlp.c_proj.weight")].wf, xo, M=B, N=d, K=mlp,
@@ -487,7 +494,7 @@ class TransformerStack:
                 dq = dict(q8_out=dU8, q8_scale=self._dq_scale[2 * i + 1:2 * i + 2], q8_amax=self._dq_amax[2 * i + 1])
             dU_has_q8 = bool(dq) and g_has_q8 and self._dq_ready
             # aux = the stored factor gelu'(u) (default) or u itself (recomputation mode): same bits either way
-            dgrad(ops.EPI_BF16_MUL_AUX if self._u_holds_grad else ops.EPI_BF16_DGELU, g0, self._n(i, "mlp.c_proj.weight"), dU,
+            dgrad(ops.EPI_BF16_MUL_AUX if self._u_holds_grad else self.epi_dgelu, g0, self._n(i, "mlp.c_proj.weight"), dU,
                   N=mlp, K=d, have_q8=g_has_q8, aux=u, q8kw=dq)
 
             mlp_probs = [(g0, h, g("mlp.c_proj.weight"), None, d, mlp), (dU, a2, g("mlp.c_fc.weight"), g("mlp.c_fc.bias"), mlp, d)]
@@ -515,7 +522,7 @@ class TransformerStack:
                                     splitk=_splitk_for(mlp, d, M))
             if self.recompute and not w8_now:          # rebuild h = gelu(u) and a2 = ln_2(xmid) for the two (bf16) weight gradients
                 before_write(h)
-                ops.gelu_bf16(u, h)
+                ops.gelu_bf16(u, h, quick=self.quick_gelu)
                 before_write(a2)
                 ops.layernorm_fwd(xmid, s.p(self._n(i, "ln_2.weight")), s.p(self._n(i, "ln_2.bias")), a2,
                                   bf.get(f"m2.{i}", (M,), F32), bf.get(f"r2.{i}", (M,), F32), M, d)
@@ -579,20 +586,25 @@ class TransformerStack:
             g0_t8_ok = t8n is not None
             if on_layer_done is not None:
                 on_side(lambda i=i: on_layer_done(i), ())     # the bucket all-reduce follows the side stream
+        # Join the side stream BEFORE the scale update: the side stream's e4m3 weight-gradient GEMMs read ``_dq_scale_inv``
+        # through device pointers when they RUN (sc_gemm8p.hip), and the low-priority side stream can lag the chain by
+        # several blocks -- an update enqueued on the chain first could replace a scale that operands quantised with the old
+        # one are still waiting to be multiplied by (advisor, round 4).
+        if overlap:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
         if self.fp8 and self._dq_on:          # next step's per-tensor scales from the maxima of the last FP8_AMAX_HISTORY steps
             ops.fp8_scale_update(self._dq_amax, self._dq_scale, self._dq_scale_inv, margin_bits=1, hist=self._dq_hist,
                                  slot=self._dq_step % self.FP8_AMAX_HISTORY)
             self._dq_step += 1
             self._dq_ready = True
-        if overlap:
-            ev = torch.cuda.Event()
-            ev.record(side)
-            main.wait_event(ev)
         if trial is not None:                     # end of a timed trial call (the side stream's work is joined above)
             trial[2].record(main)
         return dres
 
     OVERLAP_TRIAL_CALLS = (2, 4)                  # untimed warm-up calls, timed calls per schedule
+    OVERLAP_MARGIN = 0.01                         # one stream must beat the side stream by this fraction to be chosen
 
     def _overlap_auto(self, key, main):
         """SC_OVERLAP=auto: (use the side stream?, trial record or None) for this backward call of batch shape ``key``."""
@@ -617,7 +629,17 @@ class TransformerStack:
                 s["ms"][rec[0]].append(rec[1].elapsed_time(rec[2]))
             s["pending"] = []
             on, off = s["ms"][True], s["ms"][False]
-            s["choice"] = (min(on) <= min(off)) if on and off else True
+            # The side stream is the schedule of rounds 1-3 and the safe one for the big models; leave it only when one stream is
+            # faster by a clear margin (the two are within 1 % on ViT-B/16 and the trial timings carry that much noise: without
+            # a margin the choice, and with it the step time, varies from run to run -- advisor, round 4).  All ranks take rank
+            # 0's decision: the trials of a rank include its collective waits, and ranks on different schedules would only
+            # wait for each other.
+            choice = True
+            if on and off:
+                choice = not (min(off) < min(on) * (1.0 - self.OVERLAP_MARGIN))
+                s["ms_best"] = {"side_stream": round(min(on), 3), "one_stream": round(min(off), 3)}
+            from . import comm
+            s["choice"] = comm.broadcast_flag(choice)
             return s["choice"], None
         use = ((c - warm) % 2) == 0               # on, off, on, off, ...
         rec = (use, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -644,6 +666,7 @@ class PatchTransformerTower:
     (``_patchify``) and in the parameter-name prefix."""
 
     prefix = "visual."
+    quick_gelu = False          # set by the subclass before super().__init__: only the reference's towers take the config flag
 
     def __init__(self, cfg: ModelCfg, store: ParamStore, width: int, heads: int, layers: int, mlp_ratio: float,
                  tokens: int, patch_dim: int):
@@ -653,7 +676,8 @@ class PatchTransformerTower:
         self.kp = patch_dim
         self.kp_pad = store.copies[self.prefix + "conv1.weight"].k_pad
         self.stack = TransformerStack(store, self.prefix + "transformer.resblocks.", width, heads, layers,
-                                      int(width * mlp_ratio), causal=False, cls_only_last=True, res16_ok=True)
+                                      int(width * mlp_ratio), causal=False, cls_only_last=True, res16_ok=True,
+                                      quick_gelu=self.quick_gelu)
         self.bufs = _Bufs(store.device)
 
     def _n(self, leaf: str) -> str:
@@ -752,6 +776,7 @@ class VisionTower(PatchTransformerTower):
     def __init__(self, cfg: ModelCfg, store: ParamStore):
         v = cfg.vision
         self.v = v
+        self.quick_gelu = bool(getattr(cfg, "quick_gelu", False))
         super().__init__(cfg, store, v.width, v.heads, v.layers, v.mlp_ratio, v.tokens, 3 * v.patch_size * v.patch_size)
 
     def _patchify(self, images: torch.Tensor) -> torch.Tensor:
@@ -874,7 +899,7 @@ class TextTower:
         self.cfg, self.t, self.s = cfg, t, store
         self.d, self.D, self.L, self.V = t.width, cfg.embed_dim, t.context_length, t.vocab_size
         self.stack = TransformerStack(store, "transformer.resblocks.", t.width, t.heads, t.layers,
-                                      int(t.width * t.mlp_ratio), causal=True)
+                                      int(t.width * t.mlp_ratio), causal=True, quick_gelu=bool(getattr(cfg, "quick_gelu", False)))
         self.bufs = _Bufs(store.device)
 
     def param_names_head(self) -> List[str]:

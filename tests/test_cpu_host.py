@@ -238,3 +238,74 @@ def test_trainer_reads_checkpoint_and_early_stopping_config(tmp_path):
     assert Trainer(max_epochs=1, enable_checkpointing=True).checkpoint_callback is None  # nowhere to write
     d = Trainer(max_epochs=1, enable_checkpointing=True, default_root_dir=str(tmp_path)).checkpoint_callback
     assert d.dirpath == str(tmp_path / "checkpoints") and d.monitor == "val/R@1" and d.mode == "max"
+
+
+# ---------------------------------------------------------------------------------------------- round 5: checkpoint interop (f2)
+def test_resize_text_pos_embed_matches_reference(golden_dir):
+    """src/open_clip/model.py:826-860 on the fixture written by the reference's own function (make_golden_r5.py)."""
+    import numpy as np
+    from spatial_clip_amd import net
+    z = np.load(os.path.join(golden_dir, "text_pos_resize.npz"))
+    for n in (32, 128, 77):
+        sd = {"positional_embedding": torch.from_numpy(z["old"]).clone()}
+        net.resize_text_pos_embed(sd, n)
+        assert sd["positional_embedding"].shape == (n, 24)
+        assert torch.allclose(sd["positional_embedding"], torch.from_numpy(z[f"new_{n}"]), atol=1e-6, rtol=0)
+    sd = {"text.positional_embedding": torch.from_numpy(z["old"]).clone()}          # custom-text key layout
+    net.resize_text_pos_embed(sd, 32)
+    assert torch.allclose(sd["text.positional_embedding"], torch.from_numpy(z["new_32"]), atol=1e-6, rtol=0)
+
+
+def _module_tree(sd):
+    root = torch.nn.Module()
+    for k, v in sd.items():
+        parts = k.split(".")
+        m = root
+        for p_ in parts[:-1]:
+            if not hasattr(m, p_):
+                m.add_module(p_, torch.nn.Module())
+            m = getattr(m, p_)
+        m.register_parameter(parts[-1], torch.nn.Parameter(v.clone()))
+    return root
+
+
+def test_checkpoint_file_formats_of_the_reference_loader(tmp_path):
+    """open_clip.factory.load_state_dict (src/open_clip/factory.py:153-178): .safetensors, pickled state_dict, pickled
+    {'state_dict': ...} training checkpoint, and a TorchScript archive (state_dict() minus input_resolution / context_length
+    / vocab_size) all come back as the same host tensors."""
+    from safetensors.torch import save_file
+    from spatial_clip_amd import net
+    g = torch.Generator().manual_seed(0)
+    sd = {"visual.conv1.weight": torch.randn(8, 3, 4, 4, generator=g), "visual.transformer.resblocks.0.ln_1.weight": torch.randn(8, generator=g),
+          "positional_embedding": torch.randn(16, 8, generator=g), "logit_scale": torch.tensor(2.6593)}
+    f1 = str(tmp_path / "w.safetensors")
+    save_file({k: v.contiguous() for k, v in sd.items()}, f1)
+    f2 = str(tmp_path / "w.pt")
+    torch.save(sd, f2)
+    f3 = str(tmp_path / "epoch_1.pt")
+    torch.save({"epoch": 1, "name": "run", "state_dict": {"module." + k: v for k, v in sd.items()}}, f3)
+    m = _module_tree(sd)
+    for name, val in (("input_resolution", 224), ("context_length", 77), ("vocab_size", 49408)):
+        m.register_buffer(name, torch.tensor(val))
+    f4 = str(tmp_path / "openai_jit.pt")
+    torch.jit.script(m).save(f4)
+    for path in (f1, f2, f4):
+        got = net.read_checkpoint_file(path)
+        assert set(got) == set(sd), (path, sorted(got))
+        for k in sd:
+            assert torch.equal(got[k].float(), sd[k]), (path, k)
+    got = net.read_checkpoint_file(f3)
+    inner = {net.strip_checkpoint_prefix(k): v for k, v in got["state_dict"].items()}
+    assert set(inner) == set(sd) and all(torch.equal(inner[k], sd[k]) for k in sd)
+
+
+def test_quickgelu_registry_entries():
+    """model_configs/ViT-B-16-quickgelu.json, ViT-B-32-quickgelu.json, ViT-L-14-quickgelu.json: the base architecture with
+    `quick_gelu: true`; the gene variants keep the flag for the image tower."""
+    from spatial_clip_amd import model_configs as mc
+    for base in ("ViT-B-16", "ViT-B-32", "ViT-L-14"):
+        a, b = mc.get_model_config(base), mc.get_model_config(base + "-quickgelu")
+        assert not a.quick_gelu and b.quick_gelu
+        assert a.vision == b.vision and a.text == b.text and a.embed_dim == b.embed_dim
+        assert mc.get_model_config(base + "-quickgelu-gene").quick_gelu
+    assert "ViT-B-16-quickgelu" in mc.list_models()

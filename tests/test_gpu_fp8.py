@@ -482,3 +482,86 @@ def test_fp8_gelu_grad_pair_epilogue_by_table_same_bits(monkeypatch):
         res[sw] = (gd.clone(), h.clone(), h8.clone(), amax.clone())
     for x, y in zip(res["1"], res["0"]):
         assert torch.equal(x, y)
+
+
+def test_e4m3_weight_gradients_do_not_race_the_scale_update_on_the_side_stream(monkeypatch):
+    """Advisor, round 4: the side stream's e4m3 weight-gradient GEMMs read the per-tensor ``scale_inv`` through device
+    pointers when they RUN, so the end-of-backward scale update must be ordered behind the side stream.  Steps whose
+    activations grow 6x from one step to the next (every scale changes at every update), weight gradients on the side
+    stream (SC_OVERLAP=1) against the same steps on one stream (SC_OVERLAP=0): every gradient of every step bit-identical,
+    and the scales really moved."""
+    import functools
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data, losses, model_configs as mc, module, net, optim
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 256, 4, 64), text=None, gene=mc.GeneCfg(200, 64))
+    B = 128
+    base = data.synthetic_batch(B, 32, 200, K=4, step=0)
+    runs, scales = {}, {}
+    for ov in ("1", "0"):
+        monkeypatch.setenv("SC_OVERLAP", ov)
+        n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=4, precision="fp8")
+        m = module.SpatialClipLitModule(
+            n, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True),
+            functools.partial(optim.FusedAdamW, lr=0.0, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.0),
+            functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+
+        class T:
+            max_steps, max_epochs, estimated_stepping_batches = 20, None, 20
+        m.trainer = T()
+        out, sc = [], []
+        for step, gain in enumerate((1.0, 1.0, 6.0, 36.0, 1.0)):
+            db = {k: v.cuda() for k, v in base.items()}
+            # louder activations: LayerNorm is scale-invariant in its input, so the gain goes into the affines of ln_2 (a2, and
+            # through c_fc u and h) -- the next update must lower those tensors' scales; lr = 0 keeps everything else fixed
+            with torch.no_grad():
+                for i in range(cfg.vision.layers):
+                    n.store.p(f"visual.transformer.resblocks.{i}.ln_2.weight").fill_(gain)
+            loss = m.training_step(db, step)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append({k: n.store.g(k).detach().cpu().clone() for k in n.state_dict()})
+            sc.append(n.vision.stack._dq_scale.cpu().clone())
+        assert n.vision.stack._fwd_w8
+        runs[ov], scales[ov] = out, sc
+    changed = sum(int((scales["1"][i + 1] != scales["1"][i]).sum()) for i in range(1, 4))
+    assert changed >= 8, changed                                 # the scales did change between the steps
+    for step in range(5):
+        assert torch.equal(scales["1"][step], scales["0"][step]), step
+        for k in runs["1"][step]:
+            assert torch.equal(runs["1"][step][k], runs["0"][step][k]), (step, k)
+
+
+def test_encode_image_after_a_training_step_matches_a_fresh_process(tmp_path):
+    """Advisor, round 4: ``encode_image`` / ``encode_text`` call the towers directly.  They must behave as evaluation passes
+    whatever ran before: no maxima recorded, no delayed scales consumed, no per-block e4m3 copies overwritten -- the features
+    after a training step (at lr = 0) equal those of a freshly built net with the same weights, bit for bit, and the scaling
+    state is untouched."""
+    import functools
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data, losses, model_configs as mc, module, net, optim
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 256, 3, 64), text=None, gene=mc.GeneCfg(200, 64))
+    batch = {k: v.cuda() for k, v in data.synthetic_batch(128, 32, 200, K=4, step=0).items()}
+    fresh = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=6, precision="fp8")
+    f_img0 = fresh.model.encode_image(batch["images"], normalize=True)
+    f_txt0 = fresh.model.encode_text(batch["texts"], normalize=True)
+    assert float(fresh.vision.stack._dq_amax.abs().max()) == 0.0           # an evaluation pass leaves no maxima behind
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=6, precision="fp8")
+    m = module.SpatialClipLitModule(
+        n, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True),
+        functools.partial(optim.FusedAdamW, lr=0.0, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.0),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+
+    class T:
+        max_steps, max_epochs, estimated_stepping_batches = 20, None, 20
+    m.trainer = T()
+    for step in range(2):
+        m.training_step(batch, step).backward()
+    torch.cuda.synchronize()
+    st = n.vision.stack
+    assert st._dq_ready and st.fp8_train_pass
+    before = (st._dq_scale.clone(), st._dq_amax.clone(), st._dq_hist.clone())
+    f_img1 = n.model.encode_image(batch["images"], normalize=True)
+    f_txt1 = n.model.encode_text(batch["texts"], normalize=True)
+    assert not st.fp8_train_pass
+    assert torch.equal(f_img1, f_img0) and torch.equal(f_txt1, f_txt0)
+    assert all(torch.equal(a, b) for a, b in zip(before, (st._dq_scale, st._dq_amax, st._dq_hist)))

@@ -235,3 +235,39 @@ def test_augment_oracle_equals_pil_fixture_bitwise():
     except ImportError:
         return
     assert np.array_equal(mk.pil_pipeline(z["down_src"][3], z["down_params"][3], int(z["down_S"])), z["down_out"][3])
+
+
+# ---------------------------------------------------------------------------------------------- round 5: QuickGELU
+def test_resblock_quickgelu_fwd_bwd(golden_dir):
+    """The reference's ResidualAttentionBlock with act_layer = QuickGELU (transformer.py:32-35)."""
+    z = load(golden_dir, "blk_d64_quickgelu.npz")
+    p = {k[2:]: t(v).requires_grad_(True) for k, v in z.items() if k.startswith("p.")}
+    x = t(z["x"]).requires_grad_(True)
+    y = O.resblock(x, p, "", int(z["heads"]), causal=False, quick=True)
+    assert torch.allclose(y, z["y"], atol=2e-5, rtol=1e-5)
+    y.backward(z["gy"])
+    assert torch.allclose(x.grad, z["gx"], atol=5e-5, rtol=1e-4)
+    for k, v in p.items():
+        assert torch.allclose(v.grad, z["g." + k], atol=2e-4, rtol=1e-4), k
+    # ... and the erf GELU does NOT reproduce it (the fixture really exercises the flag)
+    y2 = O.resblock(t(z["x"]), {k: v.detach() for k, v in p.items()}, "", int(z["heads"]), causal=False, quick=False)
+    assert float((y2 - z["y"]).abs().max()) > 1e-3
+
+
+def test_clip_tiny_quickgelu_fwd_bwd(golden_dir):
+    """CLIP(quick_gelu=True): both reference towers switch their activation (model.py:142-145,228)."""
+    z = load(golden_dir, "clip_tiny_quickgelu_fwd_bwd.npz")
+    c = json.loads(str(z["cfg"]))
+    assert c["quick_gelu"] is True
+    cfg = _cfg_from_json(z["cfg"])
+    cfg.quick_gelu = True
+    p = {k[2:]: t(v).requires_grad_(True) for k, v in z.items() if k.startswith("p.")}
+    f = O.net_forward(z["images"], z["texts"], p, cfg)
+    assert torch.allclose(f["image_features"], z["image_features"], atol=2e-6)
+    assert torch.allclose(f["text_features"], z["text_features"], atol=2e-6)
+    loss = O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"])
+    assert abs(float(loss) - float(z["loss"])) < 2e-6
+    loss.backward()
+    for k, v in p.items():
+        g = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert torch.allclose(g, z["g." + k], atol=2e-5, rtol=1e-3), k
