@@ -161,11 +161,13 @@ def loss_delta_vs_oracle(m, n, cfg, batch_cpu, loss_kind: str, dtype: str = "bf1
                                  batch_cpu["text_tile_ids"], batch_cpu["neighbor_tile_ids"], batch_cpu["neighbor_alphas"])
         if trained:
             O.USE_ATEN_KERNELS = True
-            try:
+            O.REFERENCE_AUTOCAST_STREAM = (n.residual_stream == "bf16" and os.environ.get("SC_RES_STREAM", "bf16") == "bf16")
+            try:        # the reference's policy with the residual stream it really carries (oracle.REFERENCE_AUTOCAST_STREAM)
                 with torch.autocast("cpu", dtype=torch.bfloat16):
                     fa = O.net_forward(batch_cpu["images"], batch_cpu["texts"], p, _oracle_cfg(cfg))
             finally:
                 O.USE_ATEN_KERNELS = False
+                O.REFERENCE_AUTOCAST_STREAM = False
             policy_noise = max(float((fa["image_features"].float() - f["image_features"]).abs().max()),
                                float((fa["text_features"].float() - f["text_features"]).abs().max()))
     dfeat = max(float((f_i - f["image_features"]).abs().max()), float((f_t - f["text_features"]).abs().max()))
@@ -302,6 +304,15 @@ def main():
         print(f"bench.py: live process group has {dist.get_world_size()} ranks, wanted {args.gpus}", file=sys.stderr)
         sys.exit(2)
 
+    # What the collectives of this run really are, on rank 0's stderr and in the JSON line: backend, RCCL version, the number
+    # of ranks RCCL itself reaches (a SUM all-reduce of ones over the communicator the step uses), which code enqueues the
+    # data-path collectives and how the gradients are exchanged -- an 8-GPU run evidences itself.
+    comm_info = comm.describe()
+    note(f"process group: backend={comm_info['backend']} world_size={comm_info['world_size']} rccl_ranks={comm_info['rccl_ranks']} "
+         f"rccl_version={comm_info['rccl_version']} route={comm_info['route']} grad_exchange={comm_info['grad_exchange']}")
+    if world > 1 and comm_info["backend"] == "nccl" and comm_info["rccl_ranks"] != args.gpus:
+        print(f"bench.py: RCCL reaches {comm_info['rccl_ranks']} ranks, wanted {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     n = net.SpatialClipNet(args.model, None, n_genes=args.n_genes, seed=0, precision=args.dtype,
                            residual_stream=args.residual_stream)
     cfg = n.cfg
@@ -321,8 +332,9 @@ def main():
     m.trainer = _T()
     oc = m.configure_optimizers()
     opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
-    reducer = comm.GradBucketReducer(n.store.grad)
-    n.grad_bucket_hook = reducer.bucket_ready if comm.is_dist() else None
+    reducer = comm.make_grad_exchange(n.store)          # None at N = 1; sharded reduce-scatter / all-gather exchange by default
+    n.grad_bucket_hook = reducer.bucket_ready if reducer is not None else None
+    opt.attach_exchange(reducer)
 
     B = args.batch
     rates = data.make_gene_rates(args.n_genes)
@@ -338,7 +350,8 @@ def main():
     def step_(i):
         loss = m.training_step(batches[i % 2], i)
         loss.backward(m.root_gradient(loss))
-        reducer.finish()
+        if reducer is not None:
+            reducer.finish()
         opt.step(grad_scale=1.0 / world, max_norm=1.0)
         sched.step()
         return loss
@@ -376,12 +389,17 @@ def main():
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
     fence()
+    comm.reset_stats()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     t_host = time.perf_counter() - t0          # host time to ENQUEUE the timed steps (GPU-bound if < total)
     fence()
     dt = time.perf_counter() - t0
+    coll = {k: {"launches_per_step": round(v[0] / args.steps, 2), "mbytes_per_step": round(v[1] / args.steps / 1e6, 3)}
+            for k, v in comm.STATS.items()}
+    for k, v in coll.items():
+        note(f"collective per step and rank: {k}: {v['launches_per_step']} launches, {v['mbytes_per_step']} MB")
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step (host enqueue {t_host / args.steps * 1e3:.2f} ms/step)")
     # Per-kernel durations: the SAME K steps again with every GEMM launch bracketed by HIP events on its launch stream.
     # Kept out of the timed region above because the 2 x ~150 event markers per step perturb the GPU pipeline (~+10 %).
@@ -518,6 +536,8 @@ def main():
                           else os.environ["SC_RES_STREAM"],
                           "parallelism": f"dp{world}", "loss": float(loss.detach())},
                "n_gpus_live": dist.get_world_size() if world > 1 else 1,
+               "rccl_ranks": comm_info["rccl_ranks"],
+               "comm": {**comm_info, "collectives_per_step_and_rank": coll},
                "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                "loss_delta_vs_oracle": None if delta_init is None else delta_init["loss_delta_vs_oracle"],
                "max_abs_feature_delta": None if delta_init is None else delta_init["max_abs_feature_delta"],

@@ -365,6 +365,13 @@ int sc_grad_norm(const float* grads, long long n, float grad_scale, float max_no
 int sc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                   const float* norm_clip, void* params_bf16, void* stream);
+/* The two halves of sc_grad_norm for an optimiser that owns 1/W of every gradient bucket (reduce-scatter ->
+ * AdamW on the rank's shard -> all-gather; Lightning's DDP mean, configs/trainer/ddp.yaml:4, replaced): 1024 fp64 partial
+ * sums of squares per contiguous piece of the shard, then -- after the caller has all-reduced (SUM) the concatenated
+ * partial arrays over the ranks -- the norm of the whole averaged gradient and the clip coefficient, as sc_grad_norm. */
+int sc_grad_sumsq_partial(const float* grads, long long n, double* partial1024, void* stream);
+int sc_grad_norm_final(const double* partial, int n_partial, float grad_scale, float max_norm, float* norm_clip_out,
+                       void* stream);
 
 #ifdef __cplusplus
 }

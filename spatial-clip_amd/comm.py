@@ -480,3 +480,186 @@ class GradBucketReducer:
             else:
                 w.wait()
         self.works, self.launched = [], []
+
+
+# ---------------------------------------------------------------------------------------------- sharded gradient exchange
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class ShardedGradExchange:
+    """gradient **reduce-scatter** per bucket (overlapped with backward) -> grad-norm + AdamW on this rank's
+    1/W of every bucket -> **all-gather** of the refreshed fp32 masters per bucket, overlapped with the NEXT forward, which
+    waits per bucket (``ParamStore.wait_range``).  Replaces Lightning's DDP mean all-reduce + replicated optimiser
+    (configs/trainer/ddp.yaml:4, src/open_clip_train/main.py:300-310) with the same arithmetic: SUM over ranks, 1/W folded
+    into the clip / AdamW kernels, so the weights equal the all-reduce route's (tests/test_gpu_ddp.py).
+
+    Layout: the flat buffers are cut into static buckets of ``bucket_floats`` (rounded to a multiple of 64 W); rank r owns the
+    r-th of the W equal pieces of every bucket (both collectives run IN PLACE on the flat gradient / master buffers: the
+    reduced piece lands where the AdamW kernel reads it, the updated piece is gathered from where AdamW wrote it -- on one
+    rank both are no-ops).  Per step and rank: (W-1)/W of the gradient bytes out and in for the reduce-scatter, the same for
+    the all-gather -- the bytes of one all-reduce -- but AdamW, the norm and the Adam moments shrink to 1/W and the second
+    half travels behind the next forward instead of in front of the optimiser.
+    What is NOT done: gathering the bf16 mirror instead of the fp32 masters (half of the all-gather bytes).  The masters are
+    read in fp32 by LayerNorm / bias / embedding kernels, by the K-padded weight copies, by the e4m3 weight quantisers and by
+    every checkpoint; keeping them whole on every rank keeps all of those exact and collective-free."""
+
+    def __init__(self, store, bucket_floats: int = 16 * 1024 * 1024):
+        self.store = store
+        self.flat = store.grad
+        self.rank, self.W = world()
+        U = 64 * self.W
+        if store.total % U:
+            raise RuntimeError(f"the parameter store ({store.total} floats) was not padded for {self.W} ranks: build the model "
+                               "after comm.init_from_env()")
+        size = _round_up(max(int(bucket_floats), U), U)
+        edges = list(range(0, store.total, size)) + [store.total]
+        if len(edges) > 2 and edges[-1] - edges[-2] < size // 2:      # a short tail joins the bucket in front of it
+            edges.pop(-2)
+        self.buckets: List[Tuple[int, int]] = [(edges[i], edges[i + 1]) for i in range(len(edges) - 1)]
+        self.cuda = self.flat.is_cuda
+        self.stream = torch.cuda.Stream(device=self.flat.device, priority=-1) if self.cuda else None
+        # order in which the next forward consumes the buckets: the second tower runs first and its parameters sit at the
+        # END of the flat buffers (forward order of the vision tower, then the second tower, then logit_scale)
+        first_second = min((s.offset for s in store.specs if not s.name.startswith("visual.")), default=0)
+        k0 = next(k for k, (lo, hi) in enumerate(self.buckets) if lo <= first_second < hi)
+        self.order = list(range(k0, len(self.buckets))) + list(range(0, k0))
+        # a Linear weight's derived copies are rebuilt with the LATEST-arriving bucket it touches
+        pos = {k: i for i, k in enumerate(self.order)}
+        self._copies: List[list] = [[] for _ in self.buckets]
+        for c in store.copies.values():
+            sp = store.by_name[c.name]
+            touched = [k for k, (lo, hi) in enumerate(self.buckets) if lo < sp.offset + sp.numel and sp.offset < hi]
+            self._copies[max(touched, key=lambda k: pos[k])].append(c)
+        self._plans = [store._transpose_plan(cs) for cs in self._copies]
+        self._ready: List[Tuple[int, int]] = []
+        self._launched = [False] * len(self.buckets)
+        self._works: List = []
+        self.rs_launched = 0
+        self.ag_launched = 0
+
+    # ---- this rank's piece of bucket k, as offsets into the flat buffers
+    def piece(self, k: int) -> Tuple[int, int]:
+        lo, hi = self.buckets[k]
+        c = (hi - lo) // self.W
+        return lo + self.rank * c, lo + (self.rank + 1) * c
+
+    def shard_floats(self) -> int:
+        return self.store.total // self.W
+
+    # ---- backward side: reduce-scatter
+    def bucket_ready(self, lo: int, hi: int) -> None:
+        """Called by backward when flat_grad[lo:hi] is final (same contract as GradBucketReducer.bucket_ready)."""
+        if not is_dist():
+            return
+        self._ready.append((lo, hi))
+        self._launch_covered()
+
+    def _covered(self, lo: int, hi: int) -> bool:
+        pos = lo
+        for a, b in sorted(self._ready):
+            if a > pos:
+                break
+            pos = max(pos, b)
+            if pos >= hi:
+                return True
+        return pos >= hi
+
+    def _launch_covered(self, force: bool = False) -> None:
+        for k, (lo, hi) in enumerate(self.buckets):
+            if not self._launched[k] and (force or self._covered(lo, hi)):
+                self._launched[k] = True
+                self._works.append(self._reduce_scatter(k))
+
+    def _reduce_scatter(self, k: int):
+        lo, hi = self.buckets[k]
+        a, b = self.piece(k)
+        _count("reduce_scatter(gradient bucket)", (hi - lo) * 4)
+        self.rs_launched += 1
+        if _native is not None and self.cuda:
+            cur = torch.cuda.current_stream(self.flat.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            _native.stream.wait_event(ready)
+            _native.reduce_scatter(self.flat[lo:hi], self.flat[a:b], _native.stream)
+            done = torch.cuda.Event()
+            done.record(_native.stream)
+            return done
+        if dist.get_backend() == "gloo":          # gloo has no reduce_scatter: all-reduce the bucket, the own piece is part of it
+            return dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+        return dist.reduce_scatter_tensor(self.flat[a:b], self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self) -> None:
+        """Flush what backward did not announce and make the current stream wait for every reduce-scatter."""
+        if not is_dist():
+            return
+        self._launch_covered(force=True)
+        for w in self._works:
+            if isinstance(w, torch.cuda.Event):
+                torch.cuda.current_stream(self.flat.device).wait_event(w)
+            else:
+                w.wait()
+        self._works, self._ready = [], []
+        self._launched = [False] * len(self.buckets)
+
+    # ---- optimiser side
+    def all_reduce_partials(self, partial: torch.Tensor) -> None:
+        """SUM over ranks of the fp64 sum-of-squares partials (a few KiB) on the current stream."""
+        _count("all_reduce(grad-norm partials)", partial.numel() * 8)
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM)
+
+    def gather_bucket(self, k: int) -> None:
+        """All-gather the updated masters of bucket k (this rank's piece was just written by AdamW on the current stream) on
+        the communication stream, rebuild the bf16 operands that depend on it there, and leave an event for the forward."""
+        st = self.store
+        lo, hi = self.buckets[k]
+        a, b = self.piece(k)
+        _count("all_gather(weights bucket)", (hi - lo) * 4)
+        self.ag_launched += 1
+        if not self.cuda:
+            dist.all_gather_into_tensor(st.master[lo:hi], st.master[a:b].clone())
+            st.refresh_range(lo, hi, self._copies[k], self._plans[k])
+            return
+        cur = torch.cuda.current_stream(self.flat.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.stream.wait_event(ready)
+        with torch.cuda.stream(self.stream):
+            if _native is not None:
+                _native.all_gather(st.master[a:b], st.master[lo:hi], self.stream)
+            elif dist.get_backend() == "gloo":
+                dist.all_gather_into_tensor(st.master[lo:hi], st.master[a:b].clone())
+            else:
+                work = dist.all_gather_into_tensor(st.master[lo:hi], st.master[a:b], async_op=True)
+                work.wait()                         # the communication stream waits for RCCL's stream (no host block)
+            st.refresh_range(lo, hi, self._copies[k], self._plans[k])
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        st.pending.append((lo, hi, done))
+
+    def gather_moments(self, shard: torch.Tensor) -> torch.Tensor:
+        """A full flat-layout copy of a sharded optimiser-state buffer (checkpoints): collective, every rank calls it."""
+        full = torch.zeros(self.store.total, dtype=shard.dtype, device=shard.device)
+        off = 0
+        for k, (lo, hi) in enumerate(self.buckets):
+            c = (hi - lo) // self.W
+            dist.all_gather_into_tensor(full[lo:hi], shard[off:off + c].clone())
+            off += c
+        return full
+
+    def scatter_moments(self, full: torch.Tensor, shard: torch.Tensor) -> None:
+        off = 0
+        for k in range(len(self.buckets)):
+            a, b = self.piece(k)
+            shard[off:off + (b - a)].copy_(full[a:b])
+            off += b - a
+
+
+def make_grad_exchange(store, bucket_floats: int = 16 * 1024 * 1024):
+    """The gradient exchange of this process group: ``ShardedGradExchange`` (default) or the rounds-1-4
+    ``GradBucketReducer`` (SC_GRAD_EXCHANGE=allreduce); None without a group."""
+    if not is_dist():
+        return None
+    if grad_exchange_mode() == "allreduce":
+        return GradBucketReducer(store.grad, bucket_floats)
+    return ShardedGradExchange(store, bucket_floats)

@@ -100,6 +100,24 @@ extern "C" int sc_grad_norm(const float* grads, long long n, float grad_scale, f
     return 0;
 }
 
+// The two halves of sc_grad_norm as separate entry points, for the sharded optimiser (comm.ShardedGradExchange): every rank
+// sums the squares of ITS shard of the reduced gradient into 1024 fp64 partials per contiguous piece, the partial arrays are
+// all-reduced (SUM, fp64: a few KiB), and every rank finishes with the same global norm / clip coefficient.
+extern "C" int sc_grad_sumsq_partial(const float* grads, long long n, double* partial1024, void* stream) {
+    SC_CHECK(n > 0 && partial1024, "sc_grad_sumsq_partial: bad args");
+    sumsq_partial_kernel<<<1024, 256, 0, (hipStream_t)stream>>>(grads, n, partial1024);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_grad_norm_final(const double* partial, int n_partial, float grad_scale, float max_norm, float* norm_clip_out,
+                                  void* stream) {
+    SC_CHECK(n_partial > 0 && partial && norm_clip_out, "sc_grad_norm_final: bad args");
+    sumsq_final_kernel<<<1, 64, 0, (hipStream_t)stream>>>(partial, n_partial, grad_scale, max_norm, norm_clip_out);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                              const float* norm_clip, void* params_bf16, void* stream) {

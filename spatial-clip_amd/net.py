@@ -49,6 +49,7 @@ class _NetFn(torch.autograd.Function):
         if fg is not None:
             fg.put("image", img)
         s = torch.empty(1, dtype=torch.float32, device=img.device)
+        net.store.wait_names(["logit_scale"])
         ops.exp_scalar(net.store.p("logit_scale").view(1), s)
         net._scale = s
         # Return ALIASES, not the tensors the towers keep (tower.f): autograd stamps this node as grad_fn on the objects

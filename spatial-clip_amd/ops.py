@@ -507,6 +507,20 @@ def grad_norm(grads, n, grad_scale, max_norm, out2):
     return out2
 
 
+def grad_sumsq_partial(grads, n, partial1024):
+    """1024 fp64 partial sums of squares of grads[:n] (one contiguous piece of a rank's gradient shard)."""
+    _req(grads, torch.float32, "grads"); _req(partial1024, torch.float64, "partial")
+    check(_lib.lib().sc_grad_sumsq_partial(grads.data_ptr(), int(n), partial1024.data_ptr(), _stream()), "sc_grad_sumsq_partial")
+
+
+def grad_norm_final(partial, n_partial, grad_scale, max_norm, out2):
+    """out2 = {norm * grad_scale, clip coefficient} from (all-reduced) fp64 partial sums of squares."""
+    _req(partial, torch.float64, "partial")
+    check(_lib.lib().sc_grad_norm_final(partial.data_ptr(), int(n_partial), float(grad_scale), float(max_norm), out2.data_ptr(),
+                                        _stream()), "sc_grad_norm_final")
+    return out2
+
+
 def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_scale, norm_clip, p_bf16=None):
     check(_lib.lib().sc_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(lr), float(beta1),
                                    float(beta2), float(eps), float(wd), int(step), float(grad_scale), _ptr(norm_clip),

@@ -35,6 +35,50 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.norm_clip = torch.zeros(2, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.exchange = None        # comm.ShardedGradExchange when this rank owns 1/W of every gradient bucket
+
+    def attach_exchange(self, exchange) -> None:
+        """Data-parallel runs: hand the optimiser the gradient exchange of the process group.  With a
+        ``comm.ShardedGradExchange`` the optimiser state shrinks to this rank's 1/W of every bucket (Adam moments: 8 bytes
+        per parameter / W) and ``step`` becomes reduce-scattered gradients -> grad-norm (one tiny all-reduce) -> AdamW on the
+        shard -> all-gather of the updated masters behind the next forward.  Anything else (None, the all-reduce reducer)
+        keeps the replicated optimiser.  Call before ``load_state_dict``."""
+        from . import comm
+        if not isinstance(exchange, comm.ShardedGradExchange):
+            self.exchange = None
+            return
+        self.exchange = exchange
+        n = exchange.shard_floats()
+        dev = self.store.device
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._partials = torch.zeros(1024 * len(exchange.buckets), dtype=torch.float64, device=dev)
+
+    def _step_sharded(self, grad_scale: float, max_norm: Optional[float]) -> torch.Tensor:
+        g = self.param_groups[0]
+        st, ex = self.store, self.exchange
+        st.wait_all()               # a step without a forward in between (tests): the previous gathers must have landed
+        clip = None
+        if max_norm is not None and max_norm > 0:
+            for k in range(len(ex.buckets)):
+                a, b = ex.piece(k)
+                ops.grad_sumsq_partial(st.grad[a:b], b - a, self._partials[1024 * k:1024 * (k + 1)])
+            ex.all_reduce_partials(self._partials)
+            ops.grad_norm_final(self._partials, self._partials.numel(), grad_scale, max_norm, self.norm_clip)
+            clip = self.norm_clip
+        off = {}
+        pos = 0
+        for k in range(len(ex.buckets)):
+            a, b = ex.piece(k)
+            off[k] = pos
+            pos += b - a
+        for k in ex.order:          # in the order the next forward consumes the buckets
+            a, b = ex.piece(k)
+            m, v = self.exp_avg[off[k]:off[k] + (b - a)], self.exp_avg_sq[off[k]:off[k] + (b - a)]
+            ops.adamw_step(st.master[a:b], st.grad[a:b], m, v, b - a, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                           g["weight_decay"], self.step_count, grad_scale, clip, None)
+            ex.gather_bucket(k)
+        return self.norm_clip
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         """Gradients are overwritten by every backward; nothing to clear."""
@@ -43,6 +87,8 @@ class FusedAdamW:
         g = self.param_groups[0]
         st = self.store
         self.step_count += 1
+        if self.exchange is not None:
+            return self._step_sharded(grad_scale, max_norm)
         clip = None
         if max_norm is not None and max_norm > 0:
             ops.grad_norm(st.grad, st.total, grad_scale, max_norm, self.norm_clip)
@@ -53,13 +99,30 @@ class FusedAdamW:
         return self.norm_clip
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+        """Full flat-layout moments whatever the exchange (a checkpoint written by W ranks resumes on any W').  With the
+        sharded exchange this is a COLLECTIVE: every rank must call it (the trainer does, before rank 0 writes the file)."""
+        if self.exchange is not None:
+            m, v = self.exchange.gather_moments(self.exp_avg), self.exchange.gather_moments(self.exp_avg_sq)
+        else:
+            m, v = self.exp_avg.clone(), self.exp_avg_sq.clone()
+        return {"step": self.step_count, "exp_avg": m, "exp_avg_sq": v,
+                "param_groups": [{k: v_ for k, v_ in self.param_groups[0].items() if k != "params"}]}
 
     def load_state_dict(self, sd) -> None:
         self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        n = self.store.total
+        m, v = sd["exp_avg"], sd["exp_avg_sq"]
+        if m.numel() != n:          # a file written with another padding (other world size): the real parameters come first
+            keep = min(m.numel(), n)
+            m2, v2 = torch.zeros(n, dtype=m.dtype, device=m.device), torch.zeros(n, dtype=v.dtype, device=v.device)
+            m2[:keep], v2[:keep] = m[:keep], v[:keep]
+            m, v = m2, v2
+        if self.exchange is not None:
+            self.exchange.scatter_moments(m.to(self.exp_avg.device), self.exp_avg)
+            self.exchange.scatter_moments(v.to(self.exp_avg.device), self.exp_avg_sq)
+        else:
+            self.exp_avg.copy_(m)
+            self.exp_avg_sq.copy_(v)
 
 
 def cosine_warmup_lambda(step: int, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5) -> float:

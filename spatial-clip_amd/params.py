@@ -129,15 +129,27 @@ def build_specs(cfg: ModelCfg) -> List[ParamSpec]:
     return specs
 
 
+def _dist_world() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 class ParamStore:
-    def __init__(self, cfg: ModelCfg, device: torch.device, seed: int = 0, fp8: bool = False):
+    def __init__(self, cfg: ModelCfg, device: torch.device, seed: int = 0, fp8: bool = False, shard_world: Optional[int] = None):
         self.cfg = cfg
         self.device = device
         self.fp8 = fp8          # forward GEMMs of the transformer blocks in e4m3 (BASELINE configs[4]); see csrc/sc_fp8.hip
         self.specs = build_specs(cfg)
         self.by_name = {s.name: s for s in self.specs}
         last = self.specs[-1]
-        self.total = last.offset + _round_up(max(last.numel, 1), ALIGN)
+        # The flat buffers end on a multiple of ALIGN * W floats (W = ranks of the live process group: the launcher's
+        # comm.init_from_env runs before the model is built), so that every gradient bucket of the sharded optimiser splits
+        # into W equal, ALIGN-aligned pieces (comm.ShardedGradExchange).  The padding holds zeros and stays zero.
+        self.shard_world = int(shard_world or _dist_world())
+        self.total = _round_up(last.offset + _round_up(max(last.numel, 1), ALIGN), ALIGN * self.shard_world)
+        # weight refreshes still in flight on the communication stream: (lo, hi, event) -- the sharded optimiser all-gathers
+        # the updated masters bucket by bucket BEHIND the next forward, which waits per bucket (wait_range)
+        self.pending: List[Tuple[int, int, object]] = []
         self.master = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
         # bf16 mirror of the master buffer (same flat layout), written by the AdamW kernel: the forward operand of
@@ -161,6 +173,30 @@ class ParamStore:
     def g(self, name: str) -> torch.Tensor:
         s = self.by_name[name]
         return self.grad[s.offset:s.offset + s.numel].view(s.shape)
+
+    # ------------------------------------------------------------------ in-flight weight refreshes
+    def wait_range(self, lo: int, hi: int) -> None:
+        """Make the current stream wait for every in-flight refresh that touches flat[lo:hi] (no-op when nothing is pending:
+        the single-process and all-reduce paths never have anything)."""
+        if not self.pending:
+            return
+        keep = []
+        cur = None
+        for plo, phi, ev in self.pending:
+            if plo < hi and lo < phi:
+                cur = cur or torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+            else:
+                keep.append((plo, phi, ev))
+        self.pending = keep
+
+    def wait_names(self, names: List[str]) -> None:
+        if self.pending:
+            self.wait_range(*self.grad_range(names))
+
+    def wait_all(self) -> None:
+        if self.pending:
+            self.wait_range(0, self.total)
 
     def grad_range(self, names: List[str]) -> Tuple[int, int]:
         lo = min(self.by_name[n].offset for n in names)
@@ -191,10 +227,12 @@ class ParamStore:
         self.refresh_compute_copies()
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        self.wait_all()
         return {s.name: self.p(s.name).detach().clone() for s in self.specs}
 
     @torch.no_grad()
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        self.wait_all()
         missing = [s.name for s in self.specs if s.name not in sd]
         unexpected = [k for k in sd if k not in self.by_name]
         if strict and (missing or unexpected):
@@ -274,10 +312,11 @@ class ParamStore:
             self._add_copy("gene.fc1.weight", g.hidden, g.n_genes, need_wb=False)
             self._add_copy("gene.fc2.weight", cfg.embed_dim, g.hidden)
 
-    def _build_transpose_plan(self) -> None:
-        """Descriptor table of every transposed copy (wb of nn.Linear weights, wf of [K,N]-stored projections)."""
+    def _transpose_plan(self, copies) -> Optional[Tuple[torch.Tensor, torch.Tensor, int, int]]:
+        """Descriptor table of the transposed copies (wb of nn.Linear weights, wf of [K,N]-stored projections) of ``copies``:
+        (desc, tile prefix, entries, tiles) for ops.cast_transpose_batched, or None if there is nothing to transpose."""
         desc, prefix, tiles = [], [0], 0
-        for c in self.copies.values():
+        for c in copies:
             sp = self.by_name[c.name]
             if c.stored_kn:       # wf[n][k] = src[k][n] : src is [k_in, n_out]
                 items = [(sp.offset, c.wf, c.k_in, c.n_out, c.k_pad)]
@@ -289,27 +328,50 @@ class ParamStore:
                 desc.append([off, dst.data_ptr(), rows, cols, ldd])
                 tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
                 prefix.append(tiles)
-        self._tp_n, self._tp_tiles = len(desc), tiles
-        self._tp_desc = torch.tensor(desc, dtype=torch.int64, device=self.device)
-        self._tp_prefix = torch.tensor(prefix, dtype=torch.int32, device=self.device)
+        if not desc:
+            return None
+        return (torch.tensor(desc, dtype=torch.int64, device=self.device),
+                torch.tensor(prefix, dtype=torch.int32, device=self.device), len(desc), tiles)
 
-    def refresh_compute_copies(self, mirror_is_fresh: bool = False) -> None:
-        """fp32 master -> bf16 GEMM operands (after init, load_state_dict and every optimiser step).
-        ``mirror_is_fresh``: the AdamW kernel has just written the bf16 mirror, only padded / transposed copies remain."""
-        if not mirror_is_fresh:
-            ops.cast_pad_bf16(self.master.view(1, -1), self.master_bf16.view(1, -1), 1, self.total, self.total)
-        if getattr(self, "_tp_desc", None) is None:
-            self._build_transpose_plan()
-        if self._tp_n:
-            ops.cast_transpose_batched(self.master, self._tp_desc, self._tp_prefix, self._tp_n, self._tp_tiles,
-                                       mirror_bf16=self.master_bf16)      # the mirror is fresh at this point
+    def _refresh_copies(self, copies, plan) -> None:
+        """Everything derived from the (fresh) bf16 mirror / fp32 masters for the Linear weights in ``copies``."""
+        if plan is not None:
+            desc, prefix, n, tiles = plan
+            ops.cast_transpose_batched(self.master, desc, prefix, n, tiles, mirror_bf16=self.master_bf16)
         if self.fp8:                                      # per-output-channel e4m3 copies straight from the fp32 masters
-            for c in self.copies.values():
+            for c in copies:
                 if c.w8 is not None:
                     ops.quantize_rows_fp8(self.p(c.name).view(c.n_out, c.k_in), c.w8, c.w8s)
                 if c.wb8 is not None:                     # rows of the transposed bf16 copy = input channels
                     ops.quantize_rows_fp8(c.wb, c.wb8, c.wb8s)
-        for c in self.copies.values():
+        for c in copies:
             if not c.stored_kn and not c.wf_is_view:      # K-padded forward operand (gene.fc1, conv1 at patch 14)
                 ops.cast_pad_bf16(self.p(c.name).view(c.n_out, c.k_in), c.wf, c.n_out, c.k_in, c.k_pad,
                                   ld_src=c.k_in, ld_dst=c.k_pad)
+
+    def refresh_compute_copies(self, mirror_is_fresh: bool = False) -> None:
+        """fp32 master -> bf16 GEMM operands (after init, load_state_dict and every optimiser step).
+        ``mirror_is_fresh``: the AdamW kernel has just written the bf16 mirror, only padded / transposed copies remain."""
+        self.wait_all()
+        if not mirror_is_fresh:
+            ops.cast_pad_bf16(self.master.view(1, -1), self.master_bf16.view(1, -1), 1, self.total, self.total)
+        if getattr(self, "_tp_plan", False) is False:
+            self._tp_plan = self._transpose_plan(list(self.copies.values()))
+        self._refresh_copies(list(self.copies.values()), self._tp_plan)
+
+    def copies_ending_in(self, lo: int, hi: int):
+        """The Linear weights whose LAST element lies in flat[lo:hi] (each weight belongs to exactly one such range)."""
+        out = []
+        for c in self.copies.values():
+            sp = self.by_name[c.name]
+            if lo <= sp.offset + sp.numel - 1 < hi:
+                out.append(c)
+        return out
+
+    def refresh_range(self, lo: int, hi: int, copies, plan) -> None:
+        """The same refresh for ONE range of the flat master buffer whose fp32 values have just arrived (all-gather of the
+        sharded optimiser): bf16 mirror of flat[lo:hi], then the derived copies of ``copies`` -- the weights that are complete
+        once this range is (the caller passes, per range, the weights that END in the latest-arriving range they touch)."""
+        n = hi - lo
+        ops.cast_pad_bf16(self.master[lo:hi].view(1, -1), self.master_bf16[lo:hi].view(1, -1), 1, n, n)
+        self._refresh_copies(copies, plan)

@@ -225,6 +225,7 @@ class TransformerStack:
                                      and M % 128 == 0 and d % 16 == 0 and mlp % 16 == 0 and d >= 256 and mlp >= 256)
         self.x_in = [None] * self.layers
         for i in range(self.layers):
+            s.wait_names(self.layer_param_names(i))      # sharded optimiser: this block's refreshed weights have landed (no-op otherwise)
             self.x_in[i] = x
             a1 = self._act("a1", i, (M, d))
             m1 = bf.get(f"m1.{i}", (M,), F32)
@@ -696,6 +697,7 @@ class PatchTransformerTower:
 
     def forward(self, inp: torch.Tensor) -> torch.Tensor:
         s, d, D, L = self.s, self.d, self.D, self.L
+        s.wait_names(self.param_names_stem())
         patches = self._patchify(inp)
         B = self.B
         M, Mp = B * L, B * (L - 1)
@@ -708,6 +710,7 @@ class PatchTransformerTower:
                          bf.get("m_pre", (M,), F32), bf.get("r_pre", (M,), F32), B, L, d)
         xf = self.stack.forward(x0, B, L)
         self.xf = xf
+        s.wait_names(self.param_names_head())
         pooled = bf.get("pooled", (B, d), BF16)
         self.x_ld = d if self.stack.cls_only_last else L * d          # xf is compact [B, d] in CLS-only mode
         ops.layernorm_fwd(xf, s.p(self._n("ln_post.weight")), s.p(self._n("ln_post.bias")), pooled,
@@ -844,6 +847,7 @@ class GeneTower:
         B = x.shape[0]
         self.B = B
         bf = self.bufs
+        s.wait_names(self.param_names())
         xg = bf.get("xg", (B, self.kpad), BF16)
         ops.cast_pad_bf16(x, xg, B, g.n_genes, self.kpad)
         u1 = bf.get("u1", (B, g.hidden), BF16)
@@ -918,8 +922,10 @@ class TextTower:
         self.B, self.text = B, text
         bf = self.bufs
         x0 = bf.get("x0", (M, d), F32)
+        s.wait_names(self.param_names_stem())
         ops.token_embed_fwd(text, s.p("token_embedding.weight"), s.p("positional_embedding"), x0, B, L, d, self.V)
         xf = self.stack.forward(x0, B, L)
+        s.wait_names(self.param_names_head())
         eot = bf.get("eot", (B,), torch.int32)
         ops.argmax_rows(text, eot, B, L)
         xe = bf.get("x_eot", (B, d), F32)

@@ -177,14 +177,19 @@ class Trainer:
         sched = cfg.get("lr_scheduler", {}).get("scheduler")
         self.optimizer, self.scheduler = opt, sched
         start_epoch = 0
+        rank, W = comm.world()
+        # gradient exchange of the group (None without one): the sharded reduce-scatter / all-gather exchange by default,
+        # the bucketed all-reduce with SC_GRAD_EXCHANGE=allreduce (comm.make_grad_exchange).  Attached before a checkpoint is
+        # loaded: the sharded optimiser keeps only this rank's piece of the moments.
+        reducer = comm.make_grad_exchange(model.net.store)
+        model.net.grad_bucket_hook = reducer.bucket_ready if reducer is not None else None
+        if hasattr(opt, "attach_exchange"):
+            opt.attach_exchange(reducer)
         if ckpt_path:
             if not os.path.isfile(ckpt_path):
                 raise FileNotFoundError(f"ckpt_path {ckpt_path!r} does not exist")
             self.global_step = self.load_checkpoint(ckpt_path, model, opt, sched)
             start_epoch = self.global_step // max(n_train, 1)
-        rank, W = comm.world()
-        reducer = comm.GradBucketReducer(model.net.store.grad)
-        model.net.grad_bucket_hook = reducer.bucket_ready if comm.is_dist() else None
         vci = self.val_check_interval
         val_every = 0 if self.fast_dev_run else (int(vci) if isinstance(vci, int) and not isinstance(vci, bool)
                                                  else (max(1, int(n_train * vci)) if vci < 1.0 else 0))
@@ -205,7 +210,8 @@ class Trainer:
                 with streams.chain_stream():
                     loss = model.training_step(batch, i)
                     loss.backward(model.root_gradient(loss))
-                    reducer.finish()
+                    if reducer is not None:
+                        reducer.finish()
                     opt.step(grad_scale=1.0 / W, max_norm=self.gradient_clip_val)
                 if sched is not None:
                     sched.step()
@@ -260,9 +266,11 @@ class Trainer:
         if cb is None:
             return
         last = os.path.join(cb.dirpath, "last.ckpt")
+        # the optimiser state of a sharded optimiser is gathered by a collective: every rank forms it, rank 0 writes it
+        opt_state = opt.state_dict() if opt is not None else None
         if self.is_global_zero:
             os.makedirs(cb.dirpath, exist_ok=True)
-            self.save_checkpoint(last, model, opt, sched, self.global_step)
+            self.save_checkpoint(last, model, opt, sched, self.global_step, optimizer_state=opt_state)
         cb.last_model_path = last
         score = rec.get(cb.monitor)
         improved = isinstance(score, float) and cb.is_better(score)
@@ -271,7 +279,7 @@ class Trainer:
             score = score0
             best = os.path.join(cb.dirpath, f"epoch_{int(rec['epoch']):03d}.ckpt")
             if self.is_global_zero:
-                self.save_checkpoint(best, model, opt, sched, self.global_step)
+                self.save_checkpoint(best, model, opt, sched, self.global_step, optimizer_state=opt_state)
                 if cb.best_model_path and cb.best_model_path != best and os.path.exists(cb.best_model_path):
                     os.remove(cb.best_model_path)
             cb.best_model_path = best
@@ -280,11 +288,14 @@ class Trainer:
             torch.distributed.barrier()
 
     @staticmethod
-    def save_checkpoint(path: str, model, optimizer=None, scheduler=None, global_step: int = 0) -> None:
-        """``state_dict`` uses the reference ``CLIP.state_dict()`` key names, so the file loads into open_clip too."""
+    def save_checkpoint(path: str, model, optimizer=None, scheduler=None, global_step: int = 0, optimizer_state=None) -> None:
+        """``state_dict`` uses the reference ``CLIP.state_dict()`` key names, so the file loads into open_clip too.
+        ``optimizer_state``: what ``optimizer.state_dict()`` returned on THIS rank (with the sharded optimiser that call is a
+        collective, so a caller that writes on one rank only passes the result in)."""
         ck = {"state_dict": {k: v.cpu() for k, v in model.net.state_dict().items()}, "global_step": global_step}
         if optimizer is not None:
-            ck["optimizer"] = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in optimizer.state_dict().items()}
+            osd = optimizer_state if optimizer_state is not None else optimizer.state_dict()
+            ck["optimizer"] = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in osd.items()}
         if scheduler is not None:
             ck["scheduler_last_epoch"] = scheduler.last_epoch
         fp8 = model.net.fp8_scaling_state() if hasattr(model.net, "fp8_scaling_state") else None

@@ -199,3 +199,96 @@ def test_sync_dist_early_stop_and_best_checkpoint_agree_on_every_rank(tmp_path):
     assert r0["best"] == r1["best"] and r0["best"].endswith("epoch_001.ckpt") and r0["score"] == r1["score"] == 0.3
     assert r0["last"] == r1["last"] and r0["last"].endswith("last.ckpt")
     assert r0["files"] == ["epoch_001.ckpt", "last.ckpt"]
+
+
+# ---------------------------------------------------------------------------------------------- sharded gradient exchange
+class _FakeSpec:
+    def __init__(self, name, offset, numel):
+        self.name, self.offset, self.numel = name, offset, numel
+
+
+class _FakeStore:
+    """The attributes comm.ShardedGradExchange reads of a ParamStore, on CPU tensors (the real one needs the HIP kernels):
+    flat gradient / master buffers padded to 64 W, the spec list (which part belongs to the second tower), no derived copies."""
+
+    def __init__(self, total, world, second_at):
+        self.total = (total + 64 * world - 1) // (64 * world) * (64 * world)
+        self.grad = torch.zeros(self.total)
+        self.master = torch.zeros(self.total)
+        self.specs = [_FakeSpec("visual.w", 0, second_at), _FakeSpec("gene.w", second_at, total - second_at)]
+        self.by_name = {s.name: s for s in self.specs}
+        self.copies = {}
+        self.pending = []
+        self.refreshed = []
+
+    def _transpose_plan(self, copies):
+        return None
+
+    def refresh_range(self, lo, hi, copies, plan):
+        self.refreshed.append((lo, hi))
+
+
+def _sharded_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import comm
+    total = 5000
+    st = _FakeStore(total, world, second_at=3500)
+    g = torch.Generator().manual_seed(7)
+    base = torch.randn(st.total, generator=g)
+    st.grad.copy_(base * (rank + 1))                         # sum over ranks = base * W (W + 1) / 2
+    ex = comm.ShardedGradExchange(st, bucket_floats=1024)
+    assert all((hi - lo) % (64 * world) == 0 for lo, hi in ex.buckets)
+    assert ex.buckets[0][0] == 0 and ex.buckets[-1][1] == st.total
+    assert all(ex.buckets[i][1] == ex.buckets[i + 1][0] for i in range(len(ex.buckets) - 1))
+    k0 = next(k for k, (lo, hi) in enumerate(ex.buckets) if lo <= 3500 < hi)
+    assert ex.order[0] == k0 and sorted(ex.order) == list(range(len(ex.buckets)))     # the second tower's bucket travels first
+    # backward announces ranges back to front, in pieces that do not line up with the buckets, and forgets one
+    for lo, hi in ((3500, st.total), (2100, 3500), (900, 2100), (64, 900)):
+        ex.bucket_ready(lo, hi)
+    early = ex.rs_launched
+    assert 0 < early < len(ex.buckets)                       # complete buckets left during "backward", the first one could not
+    ex.finish()
+    assert ex.rs_launched == len(ex.buckets)
+    want = base * (world * (world + 1) / 2)
+    own = torch.zeros(st.total, dtype=torch.bool)
+    for k in range(len(ex.buckets)):
+        a, b = ex.piece(k)
+        own[a:b] = True
+        assert torch.allclose(st.grad[a:b], want[a:b], rtol=1e-6, atol=1e-6), k
+    assert int(own.sum()) == st.total // world == ex.shard_floats()
+    # "optimiser": every rank updates ITS pieces only, then the buckets are gathered in forward order
+    st.master.fill_(-1.0)
+    for k in ex.order:
+        a, b = ex.piece(k)
+        st.master[a:b] = 2.0 * st.grad[a:b] + 1.0
+        ex.gather_bucket(k)
+    assert torch.allclose(st.master, 2.0 * want + 1.0, rtol=1e-6, atol=1e-6)
+    assert [r for r in st.refreshed] == [ex.buckets[k] for k in ex.order]
+    # optimiser-state round trip through the full flat layout (checkpoints)
+    shard = torch.arange(ex.shard_floats(), dtype=torch.float32) + 10000 * rank
+    full = ex.gather_moments(shard)
+    back = torch.zeros_like(shard)
+    ex.scatter_moments(full, back)
+    assert torch.equal(back, shard)
+    ret[rank] = {"master": st.master.numpy().copy(), "full": full.numpy().copy(), "stats": dict(comm.STATS)}
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_gradient_exchange_on_gloo(world):
+    """per-bucket reduce-scatter -> update of the rank's pieces -> per-bucket all-gather, on 2 and 4 gloo
+    ranks: every rank ends with the same, fully updated buffer, the same as a SUM all-reduce + replicated update gives."""
+    mp.set_start_method("spawn", force=True)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_sharded_worker, args=(world, 29650 + world, ret), nprocs=world, join=True)
+        res = dict(ret)
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[r]["master"], res[0]["master"])
+        np.testing.assert_array_equal(res[r]["full"], res[0]["full"])
+    assert res[0]["stats"]["reduce_scatter(gradient bucket)"][0] == res[0]["stats"]["all_gather(weights bucket)"][0]

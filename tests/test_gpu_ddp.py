@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(rank, world, port, steps, B, ret):
+def _run(rank, world, port, steps, B, ret, exchange="sharded"):
     import sys
     sys.path.insert(0, ROOT)
     import functools
     import torch.distributed as dist
+    os.environ["SC_GRAD_EXCHANGE"] = exchange
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -37,8 +38,14 @@ def _run(rank, world, port, steps, B, ret):
     m.trainer = T()
     oc = m.configure_optimizers()
     opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
-    reducer = comm.GradBucketReducer(n.store.grad, bucket_floats=20000)
-    n.grad_bucket_hook = reducer.bucket_ready if world > 1 else None
+    reducer = comm.make_grad_exchange(n.store, bucket_floats=20000)          # None in the single process
+    assert (reducer is None) == (world == 1)
+    if world > 1:
+        assert isinstance(reducer, comm.ShardedGradExchange if exchange == "sharded" else comm.GradBucketReducer)
+    n.grad_bucket_hook = reducer.bucket_ready if reducer is not None else None
+    opt.attach_exchange(reducer)
+    if world > 1 and exchange == "sharded":
+        assert opt.exp_avg.numel() == n.store.total // world and len(reducer.buckets) >= 3       # Adam moments: this rank's 1/W
     losses_out = []
     for s in range(steps):
         if world > 1:
@@ -48,12 +55,16 @@ def _run(rank, world, port, steps, B, ret):
             b = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
         loss = m.training_step({k: v.cuda() for k, v in b.items()}, s)
         loss.backward()
-        reducer.finish()
+        if reducer is not None:
+            reducer.finish()
         opt.step(grad_scale=1.0 / world, max_norm=1.0)
         sched.step()
         losses_out.append(float(loss.detach()))
     torch.cuda.synchronize()
-    ret[(world, rank)] = {"loss": losses_out, "proj": n.store.p("visual.proj").cpu(),
+    osd = opt.state_dict()                       # collective with the sharded optimiser: full flat-layout moments
+    key = (world, rank) if exchange == "sharded" else (world, rank, exchange)
+    ret[key] = {"loss": losses_out, "master": n.store.master.detach().cpu(), "exp_avg": osd["exp_avg"].cpu(),
+                "exp_avg_sq": osd["exp_avg_sq"].cpu(), "proj": n.store.p("visual.proj").cpu(),
                           "fc2": n.store.p("gene.fc2.weight").cpu(), "qkv": n.store.p(
                               "visual.transformer.resblocks.0.attn.in_proj_weight").cpu()}
     if world > 1:
@@ -61,14 +72,24 @@ def _run(rank, world, port, steps, B, ret):
 
 
 def test_two_ranks_match_single_process():
+    """Two ranks (default gradient exchange: per-bucket reduce-scatter -> AdamW on the rank's pieces -> all-gather behind the
+    next forward) against one process on the concatenated batch, and against the SAME two ranks on the rounds-1-4 route
+    (bucketed SUM all-reduce + replicated AdamW): weights and Adam moments bit-identical after 3 steps."""
     mp.set_start_method("spawn", force=True)
     steps, B = 3, 8
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_run, args=(1, 0, steps, 2 * B, ret), nprocs=1, join=True)
         mp.spawn(_run, args=(2, 29713, steps, B, ret), nprocs=2, join=True)
+        mp.spawn(_run, args=(2, 29715, steps, B, ret, "allreduce"), nprocs=2, join=True)
         res = dict(ret)
     one, r0, r1 = res[(1, 0)], res[(2, 0)], res[(2, 1)]
+    a0, a1 = res[(2, 0, "allreduce")], res[(2, 1, "allreduce")]
+    for k in ("master", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(r0[k], r1[k]), f"sharded route: ranks diverged on {k}"
+        assert torch.equal(a0[k], a1[k]), f"all-reduce route: ranks diverged on {k}"
+        assert torch.equal(r0[k], a0[k]), f"the two gradient-exchange routes differ on {k}"
+    assert r0["loss"] == a0["loss"] and r1["loss"] == a1["loss"]
     for k in ("proj", "fc2", "qkv"):
         assert torch.equal(r0[k], r1[k]), f"ranks diverged on {k}"          # same reduced gradients -> same weights
         assert float((r0[k] - one[k]).abs().max()) < 3e-3, k                  # and they follow the single-process run
@@ -173,12 +194,13 @@ def test_train_entry_point_two_ranks_overlapped_gather_is_bit_identical():
 # RCCL itself: a ONE-rank nccl group with the distributed code path forced on (SC_FORCE_DIST=1) runs every collective
 # of the step -- packed all-gathers on the communication stream, reduce_scatter_tensor, bucketed async all-reduce -- on
 # the real RCCL backend; at world size 1 they are identities, so the result must equal the plain single-process run
-def _rccl_worker(rank, world, port, force, ret, native=False):
+def _rccl_worker(rank, world, port, force, ret, native=False, exchange="sharded"):
     import sys
     sys.path.insert(0, ROOT)
     import functools
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "LOCAL_RANK": "0",
-                       "WORLD_SIZE": "1", "SC_FORCE_DIST": "1" if force else "0", "SC_COMM_NATIVE": "1" if native else "0"})
+                       "WORLD_SIZE": "1", "SC_FORCE_DIST": "1" if force else "0", "SC_COMM_NATIVE": "1" if native else "0",
+                       "SC_GRAD_EXCHANGE": exchange})
     import spatial_clip_amd  # noqa: F401
     from spatial_clip_amd import comm, data, losses, model_configs as mc, module, net, optim
     comm.init_from_env()
@@ -198,23 +220,28 @@ def _rccl_worker(rank, world, port, force, ret, native=False):
     m.trainer = T()
     oc = m.configure_optimizers()
     opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
-    reducer = comm.GradBucketReducer(n.store.grad, bucket_floats=20000)
-    n.grad_bucket_hook = reducer.bucket_ready if comm.is_dist() else None
+    reducer = comm.make_grad_exchange(n.store, bucket_floats=20000)
+    assert (reducer is not None) == bool(force)
+    n.grad_bucket_hook = reducer.bucket_ready if reducer is not None else None
+    opt.attach_exchange(reducer)
     ls = []
     for s in range(3):
         b = data.synthetic_batch(16, 32, 200, 4, s)
         loss = m.training_step({k: v.cuda() for k, v in b.items()}, s)
         loss.backward()
-        reducer.finish()
+        if reducer is not None:
+            reducer.finish()
         opt.step(grad_scale=1.0, max_norm=1.0)
         sched.step()
         ls.append(float(loss.detach()))
     torch.cuda.synchronize()
     nat = comm.native()
     assert (nat is not None) == bool(native and force)
-    ret["native" if native else force] = {"w": n.store.master.detach().cpu(), "loss": ls,
-                                          "gathers": 0 if m._feature_gather is None else m._feature_gather.launched,
-                                          "native_calls": 0 if nat is None else nat.launched}
+    key = ("native" if native else force) if exchange == "sharded" else exchange
+    ret[key] = {"w": n.store.master.detach().cpu(), "loss": ls,
+                "gathers": 0 if m._feature_gather is None else m._feature_gather.launched,
+                "native_calls": 0 if nat is None else nat.launched, "stats": {k: list(v) for k, v in comm.STATS.items()},
+                "info": comm.describe() if force else None}
     comm.shutdown()
     assert comm.native() is None
 
@@ -226,14 +253,24 @@ def test_rccl_one_rank_group_runs_every_collective_and_changes_nothing():
         mp.spawn(_rccl_worker, args=(1, 29751, True, ret), nprocs=1, join=True)
         mp.spawn(_rccl_worker, args=(1, 29752, False, ret), nprocs=1, join=True)
         mp.spawn(_rccl_worker, args=(1, 29753, True, ret, True), nprocs=1, join=True)
+        mp.spawn(_rccl_worker, args=(1, 29754, True, ret, False, "allreduce"), nprocs=1, join=True)
         res = dict(ret)
     assert res[True]["gathers"] == 6 and res[False]["gathers"] == 0
     assert res[True]["loss"] == res[False]["loss"]
     assert torch.equal(res[True]["w"], res[False]["w"])
+    # the default gradient exchange ran on RCCL: reduce-scatters and weight all-gathers, no bucket all-reduce; the rounds-1-4
+    # route (SC_GRAD_EXCHANGE=allreduce) the other way round; same weights
+    st = res[True]["stats"]
+    assert st["reduce_scatter(gradient bucket)"][0] >= 9 and st["all_gather(weights bucket)"][0] == st["reduce_scatter(gradient bucket)"][0]
+    assert "all_reduce(gradient bucket)" not in st
+    assert res[True]["info"]["backend"] == "nccl" and res[True]["info"]["rccl_ranks"] == 1 and res[True]["info"]["grad_exchange"] == "sharded"
+    ar = res["allreduce"]
+    assert ar["stats"]["all_reduce(gradient bucket)"][0] >= 3 and "all_gather(weights bucket)" not in ar["stats"]
+    assert ar["loss"] == res[False]["loss"] and torch.equal(ar["w"], res[False]["w"])
     # the same step with the collectives issued by the kernel library's own RCCL entry points (SC_COMM_NATIVE=1:
     # sc_comm_init + sc_allgather_feats_async / sc_reduce_scatter_grads_async / sc_allreduce_sum_async on explicit streams)
     nat = res["native"]
-    assert nat["gathers"] == 6 and nat["native_calls"] >= 6 + 3 + 3          # gathers + reduce-scatters + >= 1 bucket per step
+    assert nat["gathers"] == 6 and nat["native_calls"] >= 6 + 3 + 2 * 9      # gathers + reduce-scatters + per step >= 3 gradient buckets, each a reduce-scatter and an all-gather
     assert nat["loss"] == res[False]["loss"] and torch.equal(nat["w"], res[False]["w"])
 
 

@@ -1,0 +1,50 @@
+#!/bin/bash
+# One parametrised GPU-session script (replaces the per-session tools/gpu_r*.sh of rounds 3-4).
+#   gpurun --timeout N -- 'bash tools/gpu_run.sh <tag> <step> [<step> ...]'
+# Every step writes under gpurun_out/<tag>/; steps are joined with && semantics (set -e): a failed or killed GPU step ends
+# the session.  Steps:
+#   tests:<pytest -k expression or file list>   pytest -m gpu on the given selection (quote spaces as '+')
+#   bench[:extra args]                           python bench.py --steps 20 --warmup 5 [extra]
+#   benchq[:extra args]                          quick bench line: no CPU baseline, no oracle, no kernel events
+#   prof[:single|side]                           rocprofv3 --kernel-trace --stats of the bench command (SC_OVERLAP=0 / default)
+#   pmc                                          the FETCH_SIZE / WRITE_SIZE / MFMA PMC passes + summaries
+#   py:<script and args>                         python <script ...> (tools/*.py micro-benchmarks)
+set -e -o pipefail
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+R=$PWD
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+for STEP in "$@"; do
+  KIND=${STEP%%:*}
+  ARG=""; [[ "$STEP" == *:* ]] && ARG=${STEP#*:}
+  ARG=${ARG//+/ }
+  echo "=== [$TAG] $KIND $ARG ($(date +%T))"
+  case $KIND in
+    tests)  timeout -k 10 1100 python -m pytest $ARG -m gpu -x -q -s 2>&1 | tee "$OUT/tests_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-60).log" | tail -40 ;;
+    bench)  timeout -k 10 900 python bench.py --steps 20 --warmup 5 $ARG > "$OUT/bench_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40).json" 2> "$OUT/bench_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40).err" ; tail -c 600 "$OUT"/bench_*.json | tail -5 ;;
+    benchq) timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loss-delta --no-kernel-events $ARG 2> "$OUT/benchq.err" | tee -a "$OUT/benchq.jsonl" | cut -c1-400 ;;
+    prof)
+      MODE=${ARG:-single}
+      D=$PWD/$OUT/prof_$MODE; rm -rf $D
+      if [ "$MODE" = single ]; then export SC_OVERLAP=0; else unset SC_OVERLAP; fi
+      (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o s -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-events --no-loss-delta > $R/$OUT/prof_$MODE.log 2>&1)
+      unset SC_OVERLAP
+      find $D -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_$MODE.csv" \;
+      find $D -name '*kernel_trace.csv' -size +20M -delete
+      head -30 "$OUT/kernel_stats_$MODE.csv" | cut -c1-200 ;;
+    pmc)
+      export SC_OVERLAP=0
+      B="python3 $R/bench.py --no-cpu-baseline --no-kernel-events --no-loss-delta"
+      (cd /tmp && timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_f -o f -- $B --steps 3 --warmup 1 > $R/$OUT/pmc_f.log 2>&1)
+      (cd /tmp && timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_w -o w -- $B --steps 3 --warmup 1 > $R/$OUT/pmc_w.log 2>&1)
+      (cd /tmp && timeout -k 10 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$OUT/pmc_m -o m -- $B --steps 2 --warmup 1 > $R/$OUT/pmc_m.log 2>&1)
+      unset SC_OVERLAP
+      python tools/pmc_summary.py $(find $OUT/pmc_f -name "f_counter_collection.csv") $(find $OUT/pmc_w -name "w_counter_collection.csv") $OUT/pmc_traffic_summary.json > $OUT/pmc_traffic.txt 2>&1; head -14 $OUT/pmc_traffic.txt
+      python tools/pmc_generic.py $OUT/pmc_mfma_summary.json "$OUT/pmc_m/**/m_counter_collection.csv" > $OUT/pmc_mfma.txt 2>&1; head -14 $OUT/pmc_mfma.txt
+      find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
+    py)     timeout -k 10 900 python $ARG 2>&1 | tee "$OUT/py_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-60).log" | tail -60 ;;
+    *) echo "unknown step $KIND"; exit 2 ;;
+  esac
+done
+echo "=== [$TAG] done ($(date +%T))"
