@@ -170,10 +170,12 @@ def loss_delta_vs_oracle(m, n, cfg, batch_cpu, loss_kind: str, dtype: str = "bf1
                 O.REFERENCE_AUTOCAST_STREAM = False
             policy_noise = max(float((fa["image_features"].float() - f["image_features"]).abs().max()),
                                float((fa["text_features"].float() - f["text_features"]).abs().max()))
-    dfeat = max(float((f_i - f["image_features"]).abs().max()), float((f_t - f["text_features"]).abs().max()))
+    d_img, d_txt = float((f_i - f["image_features"]).abs().max()), float((f_t - f["text_features"]).abs().max())
+    dfeat = max(d_img, d_txt)
     ftol = par.trained_point_feature_bound(policy_noise, dtype) if trained else par.FEATURE_TOLERANCE[dtype]
     dl = abs(hip_loss - float(ref))
     res = {"loss_hip": hip_loss, "loss_oracle_fp32": float(ref), "loss_delta_vs_oracle": dl, "max_abs_feature_delta": dfeat,
+           "max_abs_image_feature_delta": d_img, "max_abs_second_tower_feature_delta": d_txt,
            "batch": int(batch_cpu["images"].shape[0]), "point": point, "tolerance": par.LOSS_TOLERANCE[dtype],
            "feature_tolerance": ftol,
            "loss_within_tolerance": bool(dl <= par.LOSS_TOLERANCE[dtype]),

@@ -507,6 +507,11 @@ extern "C" int sc_attn_fwd(const void* qkv, void* out, float* lse, int B, int L,
         SC_LAUNCH_CHECK();
         return 0;
     }
+    const char* p2 = getenv("SC_ATTN_PERSIST2");                 // A/B switch of the 225..288-token persistent kernel
+    if (persist_on && !(p2 && p2[0] == '0') && sc_attn_fwd_persistent2(qkv, out, lse, B, L, Lq, H, dh, causal, st)) {
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     const int Lp = (L + 31) & ~31;
     const size_t lds = (size_t)2 * Lp * dh * 2;
     const float scale = 1.0f / sqrtf((float)dh);

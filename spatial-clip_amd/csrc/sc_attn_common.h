@@ -10,6 +10,10 @@
 int sc_attn_fwd_persistent(const void* qkv, void* out, float* lse, int B, int L, int Lq, int H, int dh, int causal,
                            hipStream_t st);
 
+// sc_attention_p2.hip (round 5): the same for 224 < L <= 288 (ViT-L/14's 257 tokens): two query tiles per compute wave, one V image
+int sc_attn_fwd_persistent2(const void* qkv, void* out, float* lse, int B, int L, int Lq, int H, int dh, int causal,
+                            hipStream_t st);
+
 // sc_attention_bwd1.hip: single-pass backward (dQ accumulated in LDS); 1 = launched, 0 = shape out of range
 int sc_attn_bwd_single_pass(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                             int B, int L, int Lq, int H, int dh, int causal, hipStream_t st);

@@ -233,10 +233,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs g) {
     const int li = lane & 15, lg = lane >> 4;
 
     int idx = sc_xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = idx % g.ntn;
-    idx /= g.ntn;
-    const int tm = idx % g.ntm;
-    const int z = idx / g.ntm;
+    int tn, tm, z;
+    if (g.col_group > 0) {                                       // column-group walk (splitk == 1): sc_gemm_common.h
+        sc_tile_colgroup(idx, g, tm, tn);
+        z = 0;
+    } else {
+        tn = idx % g.ntn;
+        idx /= g.ntn;
+        tm = idx % g.ntm;
+        z = idx / g.ntm;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
@@ -1377,6 +1383,12 @@ int sc_gemm8p_tn_fp8(GemmArgs& g, int splitk_req, float* slabs, hipStream_t st) 
     return 1;
 }
 
+// Which launches take the column-group walk by default (measured per launch class: profiles/r05_gemm_colgroup.txt).
+static int sc_colgroup_default(int epi, const GemmArgs& g) {
+    (void)epi; (void)g;
+    return 0;
+}
+
 int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, hipStream_t st) {
     if (g.M < 256 || g.N < 192 || (g.K % BK) != 0) return 0;
     if (mode == SC_GEMM_TN && (epi != SC_EPI_F32 || (g.M % 8) != 0 || (g.N % 8) != 0)) return 0;
@@ -1413,6 +1425,27 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
         if (epi == SC_EPI_BF16_BIAS) return launch_persistent<SC_EPI_BF16_BIAS>(g, nblocks, st);
         if (epi == SC_EPI_GELU_PAIR) return launch_persistent<SC_EPI_GELU_PAIR>(g, nblocks, st);      // +1.5 % at 9.2 rounds
         if (epi == SC_EPI_GELU_GRAD_PAIR) return launch_persistent<SC_EPI_GELU_GRAD_PAIR>(g, nblocks, st);
+    }
+    // Tile walk of the non-persistent kernel: SC_GEMM_COLGROUP="<epi>:<Gc>[,<epi>:<Gc>...]" (A/B switch, read per call)
+    // walks the named epilogues' launches in column groups of Gc tiles inside per-XCD row bands (sc_tile_colgroup).
+    g.col_group = 0;
+    if (splitk == 1 && g.ntn > 1) {
+        int gc = sc_colgroup_default(epi, g);
+        if (const char* sw = getenv("SC_GEMM_COLGROUP")) {
+            for (const char* p = sw; *p;) {
+                char* e = nullptr;
+                const long ep = strtol(p, &e, 10);
+                if (e == p || *e != ':') break;
+                const long v = strtol(e + 1, &e, 10);
+                if (ep == epi || ep == -1) gc = (int)v;
+                p = (*e == ',') ? e + 1 : e;
+                if (*e != ',') break;
+            }
+        }
+        if (gc > 0 && gc < g.ntn) {
+            g.col_group = gc;
+            g.band_rows = (g.ntm + 7) / 8;                       // an XCD's contiguous share of the remapped tile list
+        }
     }
     int rc = 0;
 #define SC_CASE(EPI) \

@@ -47,7 +47,33 @@ struct GemmArgs {
     // activation of the GELU epilogues: 0 = exact-erf GELU (nn.GELU), 1 = QuickGELU x * sigmoid(1.702 x) (the ABI's
     // SC_EPI_QGELU_* values select the same template instance with act = 1; wave-uniform, so the choice is a scalar branch)
     int act = 0;
+    // tile walk of gemm8p_kernel (round 5): 0 = row-major over the whole matrix (an XCD's consecutive tiles sweep all ntn
+    // column tiles, i.e. ALL of B, every ~2.7 tile rows); Gc > 0 = an XCD's band of `band_rows` tile rows is walked column
+    // group by column group (Gc column tiles: a B sub-panel that stays in the XCD's 4-MB L2 while the band's rows stream by)
+    int col_group = 0;
+    int band_rows = 0;
 };
+
+// (tm, tn) of remapped tile index idx under the column-group walk (splitk == 1)
+SC_DEVICE void sc_tile_colgroup(int idx, const GemmArgs& g, int& tm, int& tn) {
+    const int band_tiles = g.band_rows * g.ntn;
+    const int band = idx / band_tiles;
+    const int r = idx - band * band_tiles;
+    const int row0 = band * g.band_rows;
+    const int rows = min(g.band_rows, g.ntm - row0);
+    const int nfg = g.ntn / g.col_group;                       // full groups; the last one may be narrower
+    const int full = rows * g.col_group * nfg;
+    if (r < full) {
+        const int gsz = rows * g.col_group;
+        const int grp = r / gsz, rr = r - grp * gsz;
+        tm = row0 + rr / g.col_group;
+        tn = grp * g.col_group + rr % g.col_group;
+    } else {
+        const int rem = g.ntn - nfg * g.col_group, r2 = r - full;
+        tm = row0 + r2 / rem;
+        tn = nfg * g.col_group + r2 % rem;
+    }
+}
 
 // ---- GELU by table (round 4) ----
 // The GELU epilogues evaluate gelu / gelu' of u AFTER u has been rounded to bf16, and store bf16: both are functions of 16 bits.

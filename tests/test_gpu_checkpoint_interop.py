@@ -130,25 +130,29 @@ def test_reference_clip_tiny_quickgelu_forward_backward(golden_dir, recompute):
     assert abs(float(out["loss"].detach()) - float(z["loss"])) < 4e-3
     out["loss"].backward()
     torch.cuda.synchronize()
-    bad, worst = [], 0.0
-    for k in n.store.by_name:
-        g_ref = z["g." + k].double()
-        g = n.store.g(k).cpu().double()
-        rel = float((g - g_ref).norm() / g_ref.norm().clamp_min(1e-9))
-        worst = max(worst, rel)
-        if rel > 0.06 and float(g_ref.norm()) > 1e-5:
-            bad.append((k, rel, float(g_ref.norm())))
-    print(f"[quick_gelu, recompute={recompute}] worst relative L2 gradient error vs the reference: {worst:.4f}")
-    assert not bad, bad
-    # the flag matters: the same weights through an erf-GELU net give other features
+
+    def grad_errors(netobj):
+        e = {}
+        for k in netobj.store.by_name:
+            g_ref = z["g." + k].double()
+            if float(g_ref.norm()) > 1e-5:
+                e[k] = float((netobj.store.g(k).cpu().double() - g_ref).norm() / g_ref.norm())
+        return e
+    e = grad_errors(n)
+    worst, med = max(e.values()), float(np.median(list(e.values())))
+    print(f"[quick_gelu, recompute={recompute}] relative L2 gradient error vs the reference: median {med:.4f}, worst {worst:.4f}")
+    # measured 0.7 % / 1.7 %.  The same weights through an erf-GELU net sit at 2.4 % / 4.3 % from this fixture even in fp32
+    # (oracle with quick=False), so these bounds separate the two activations
+    assert med <= 0.015 and worst <= 0.03, (med, worst, max(e, key=e.get))
+    # ... and the flag matters on the HIP path: an erf-GELU net with these weights misses the fixture's gradients
     cfg2 = mc.ModelCfg(cfg.embed_dim, cfg.vision, cfg.text, None, cfg.init_logit_scale, False)
-    n2 = net.SpatialClipNet("custom", None, model_cfg=cfg2)
+    n2 = net.SpatialClipNet("custom", None, model_cfg=cfg2, grad_checkpointing=recompute)
     n2.load_state_dict({k[2:]: v for k, v in z.items() if k.startswith("p.")})
-    f2 = n2.model.encode_image(z["images"].cuda(), normalize=True)
-    f1 = n.model.encode_image(z["images"].cuda(), normalize=True)
-    e_quick = float((f1.cpu() - z["image_features"]).abs().max())
-    e_erf = float((f2.cpu() - z["image_features"]).abs().max())
-    assert e_erf > 2.0 * e_quick and float((f1 - f2).abs().max()) > 2e-3, (e_quick, e_erf)
+    m2 = module.SpatialClipLitModule(n2, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True), None, None)
+    m2.model_step({"images": z["images"].cuda(), "texts": z["texts"].cuda()})["loss"].backward()
+    torch.cuda.synchronize()
+    e2 = grad_errors(n2)
+    assert float(np.median(list(e2.values()))) > 0.018, float(np.median(list(e2.values())))
 
 
 @pytest.mark.parametrize("fmt", ["safetensors", "pickle", "lightning", "torchscript"])

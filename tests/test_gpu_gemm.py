@@ -322,3 +322,37 @@ def test_wgrad_group_exact(K, splitk, shapes):
             assert torch.equal(dw.cpu(), w), (K, splitk, M, N, rep)
             if db is not None:
                 assert torch.equal(db.cpu(), b), (K, splitk, M, N, rep, "bias")
+
+
+@pytest.mark.parametrize("epi_name,M,N,K,gc", [("plain", 256 * 9 + 40, 256 * 5, 128, 2), ("plain", 256 * 17, 256 * 12, 64, 4),
+                                               ("pair", 256 * 11 + 8, 256 * 7 + 64, 192, 3), ("mul_aux", 256 * 23, 256 * 12, 64, 6),
+                                               ("bias_res", 256 * 9, 256 * 3, 256, 1), ("plain", 256 * 3, 256 * 4, 64, 3)])
+def test_column_group_tile_walk_is_a_permutation_of_the_tiles(monkeypatch, epi_name, M, N, K, gc):
+    """Round 5: SC_GEMM_COLGROUP walks the output tiles of the non-persistent 256-tile kernel in column groups inside per-XCD
+    row bands.  Every tile must still be computed exactly once: results bit-identical to the row-major walk on ragged tile
+    grids (rows not a multiple of the 8 bands, columns not a multiple of the group, fewer rows than bands)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    a, b = _rand((M, K), g), _rand((N, K), g, 0.2)
+    epi = {"plain": ops.EPI_BF16, "pair": ops.EPI_GELU_GRAD_PAIR, "mul_aux": ops.EPI_BF16_MUL_AUX, "bias_res": ops.EPI_BF16_BIAS_RES}[epi_name]
+    kw = {}
+    if epi_name in ("pair", "bias_res"):
+        kw["bias"] = torch.randn(N, generator=g).cuda()
+    if epi_name == "mul_aux":
+        kw["aux"] = _rand((M, N), g).cuda()
+    if epi_name == "bias_res":
+        kw["res"] = _rand((M, N), g).cuda()
+    outs = []
+    for sw in (f"{epi}:0", f"{epi}:{gc}"):
+        monkeypatch.setenv("SC_GEMM_COLGROUP", sw)
+        # (every shape here has < 1024 tiles: the launch takes the non-persistent kernel, where the walk lives)
+        o = torch.full((M, N), 9.0, dtype=torch.bfloat16, device="cuda")
+        o2 = torch.full((M, N), 9.0, dtype=torch.bfloat16, device="cuda") if epi_name == "pair" else None
+        ops.gemm(ops.NT, epi, a.cuda(), b.cuda(), o, M=M, N=N, K=K, out2=o2, **kw)
+        outs.append((o.clone(), None if o2 is None else o2.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1])
+    ref = a.float() @ b.float().t()
+    if epi_name == "plain":
+        torch.testing.assert_close(outs[1][0].float().cpu(), ref.to(torch.bfloat16).float(), atol=3e-2, rtol=2e-2)

@@ -56,7 +56,11 @@ def test_attention_fwd_bwd(B, L, H, dh, causal):
 @pytest.mark.parametrize("B,L,H,causal,q_rows", [(64, 197, 12, False, 0), (110, 77, 8, True, 0), (70, 197, 12, False, 1),
                                                  (300, 33, 3, False, 0), (37, 224, 9, True, 0), (301, 33, 1, True, 0),
                                                  (130, 65, 3, True, 0), (90, 223, 3, False, 0), (280, 223, 1, True, 0),
-                                                 (257, 65, 1, False, 1)])
+                                                 (257, 65, 1, False, 1),
+                                                 # round 5: 225..288 tokens (sc_attention_p2.hip: two query tiles per wave, one V image)
+                                                 (40, 257, 16, False, 0), (300, 257, 1, False, 0), (70, 225, 4, True, 0),
+                                                 (33, 288, 9, False, 0), (270, 240, 1, True, 0), (50, 257, 16, False, 1),
+                                                 (20, 256, 16, False, 0), (40, 273, 7, False, 30)])
 def test_attention_fwd_persistent_walks_many_heads(B, L, H, causal, q_rows):
     """More heads than CUs: every persistent workgroup walks several heads through its LDS double buffer (the DMA of
     head i+1 lands while head i computes; counted vmcnt past the previous head's stores).  Run twice: the second launch
@@ -83,7 +87,8 @@ def test_attention_fwd_persistent_walks_many_heads(B, L, H, causal, q_rows):
 
 
 @pytest.mark.parametrize("B,L,H,causal,q_rows", [(70, 197, 12, False, 0), (301, 33, 1, True, 0), (130, 65, 3, True, 0),
-                                                 (90, 223, 3, False, 0), (70, 197, 12, False, 1)])
+                                                 (90, 223, 3, False, 0), (70, 197, 12, False, 1),
+                                                 (24, 257, 16, False, 0), (290, 257, 1, False, 0), (40, 241, 5, True, 0)])
 def test_attention_fwd_persistent_vs_per_head_kernel(B, L, H, causal, q_rows, monkeypatch):
     """SC_ATTN_PERSIST is read per call: the same inputs through the persistent LDS-DMA kernel and through the
     one-workgroup-per-head kernel must agree to bf16 rounding of the output (different softmax schedule: two-pass vs

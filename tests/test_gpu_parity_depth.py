@@ -44,16 +44,16 @@ def _oracle_loss(kind, f, batch):
 
 # ------------------------------------------------------------------------------------------------------------------ (a)
 # The yardstick is the reference's OWN precision policy at this geometry: the fp32 oracle run under torch.autocast(bf16)
-# (Lightning `precision: bf16-mixed`), once with the fp32 residual stream plain autocast keeps and once with the bf16 stream
-# the reference's LayerNorm / conv1 really produce (oracle.REFERENCE_AUTOCAST_STREAM).  Measured on the GPU box (MI355X +
-# EPYC host, B = 16, 157 tensors; profiles/r05_fulldepth_gradients.txt), relative L2 against the fp32 oracle, median / worst:
-#   ClipLoss     reference policy 2.55 % / 2.98 % (fp32 stream), 2.64 % / 14.9 % (bf16 stream; one tiny LayerNorm bias)
-#                this build       2.73 % / 4.20 % (fp32 stream), 3.29 % / 4.38 % (bf16 stream, the default)
-#   SpatialLoss  reference policy 2.33 % / 2.69 %,               2.47 % / 10.5 %
-#                this build       2.05 % / 3.06 %,               2.42 % / 3.57 %
-# bf16 GEMM operands at width 768 put 2-3 % on every tensor whoever multiplies them: the verdict's 3 % ceiling is below what
-# the reference's own autocast does here.  Stated bound: median within 1.35 x the reference policy's median for the same
-# stream (measured <= 1.25 x), no tensor beyond 5 %.
+# (Lightning `precision: bf16-mixed`; the oracle's ATen form calls F.linear / F.layer_norm / SDPA / F.gelu, the ops the
+# reference's modules call, so autocast casts exactly what it casts there), once with the fp32 residual stream that plain
+# functional code keeps and once with the bf16 stream the reference's LayerNorm / conv1 really produce
+# (oracle.REFERENCE_AUTOCAST_STREAM).  Relative L2 per parameter tensor against the fp32 oracle, median / worst over the
+# 157 tensors, B = 16 (profiles/r05_fulldepth_gradients.txt):
+#   ClipLoss     reference policy 3.0 % / 3.5 % (fp32 stream), 4.8 % / 51 % (bf16 stream = the reference as configured)
+#                this build       2.7 % / 4.2 % (fp32 stream), 3.3 % / 4.4 % (bf16 stream, the default)
+# bf16 GEMM operands at width 768 put ~3 % on every tensor whoever multiplies them: the verdict's 3 % ceiling is below what
+# the reference's own autocast does here.  Stated bound: median no worse than 1.35 x the fp32-stream reference policy's
+# (the quieter of the two yardsticks; measured <= 1.15 x), no tensor beyond 5 %.
 GRAD_MEDIAN_OVER_YARDSTICK = 1.35
 GRAD_REL_L2_WORST = 0.05
 
@@ -126,7 +126,7 @@ def test_vitb16_full_depth_gradients_vs_fp32_oracle(loss_kind):
         report.append((stream, med, wmax, worst))
     assert len(keys) >= 150, len(keys)
     for stream, med, wmax, worst in report:
-        assert med <= GRAD_MEDIAN_OVER_YARDSTICK * yard[stream][0], (stream, med, yard[stream])
+        assert med <= GRAD_MEDIAN_OVER_YARDSTICK * yard["fp32"][0], (stream, med, yard)
         assert wmax <= GRAD_REL_L2_WORST, (stream, wmax, worst)
 
 

@@ -211,7 +211,7 @@ def test_aten_kernel_mode_matches_plain_mode():
         assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5          # lr 1e-2: three steps amplify fp32 rounding
         assert abs(float(a["grad_norm"]) - float(b["grad_norm"])) < 1e-5 * max(1.0, float(a["grad_norm"]))
     for k in pa:
-        assert float((pa[k] - pb[k]).abs().max()) < 2e-5, k
+        assert float((pa[k] - pb[k]).abs().max()) < 4e-5, k          # (F.linear adds the bias inside addmm: another rounding order)
 
 
 def test_augment_oracle_equals_pil_fixture_bitwise():

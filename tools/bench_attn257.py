@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Attention forward / backward alone on the ViT-L/14 shape (B=256, L=257, H=16, dh=64): the per-head kernels (the persistent ones
-stop at L = 224)."""
+"""Attention forward / backward alone on the ViT-L/14 shape (B=256, L=257, H=16, dh=64): the persistent 225..288-token kernels
+of round 5 (sc_attention_p2.hip, ...) against the per-head kernels (SC_ATTN_PERSIST2=0 / SC_ATTN_BWD4=0), interleaved."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,9 +28,12 @@ def timeit(fn, name):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    print(f"{name:24s} {e0.elapsed_time(e1) / n * 1e3:8.1f} us", flush=True)
+    print(f"{name:34s} {e0.elapsed_time(e1) / n * 1e3:8.1f} us", flush=True)
 
 
 for rep in range(int(os.environ.get("REPS", 2))):
-    timeit(lambda: ops.attn_fwd(qkv, B, L, H, dh, False, out=out, lse=lse), "fwd")
-    timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, dh, False, dqkv=dqkv, delta=delta), "bwd")
+    for sw, tag in (("1", "persistent (round 5)"), ("0", "per-head kernels")):
+        os.environ["SC_ATTN_PERSIST2"] = sw
+        os.environ["SC_ATTN_BWD4"] = sw
+        timeit(lambda: ops.attn_fwd(qkv, B, L, H, dh, False, out=out, lse=lse), f"fwd  {tag}")
+        timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, dh, False, dqkv=dqkv, delta=delta), f"bwd  {tag}")

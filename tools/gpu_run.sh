@@ -3,7 +3,7 @@
 #   gpurun --timeout N -- 'bash tools/gpu_run.sh <tag> <step> [<step> ...]'
 # Every step writes under gpurun_out/<tag>/; steps are joined with && semantics (set -e): a failed or killed GPU step ends
 # the session.  Steps:
-#   tests:<pytest -k expression or file list>   pytest -m gpu on the given selection (quote spaces as '+')
+#   tests:<files>[@<-k expression>]              pytest -m gpu on the given files (spaces written as '+')
 #   bench[:extra args]                           python bench.py --steps 20 --warmup 5 [extra]
 #   benchq[:extra args]                          quick bench line: no CPU baseline, no oracle, no kernel events
 #   prof[:single|side]                           rocprofv3 --kernel-trace --stats of the bench command (SC_OVERLAP=0 / default)
@@ -21,7 +21,11 @@ for STEP in "$@"; do
   ARG=${ARG//+/ }
   echo "=== [$TAG] $KIND $ARG ($(date +%T))"
   case $KIND in
-    tests)  timeout -k 10 1100 python -m pytest $ARG -m gpu -x -q -s 2>&1 | tee "$OUT/tests_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-60).log" | tail -40 ;;
+    tests)  # tests:<files>[@<-k expression>]
+      FILES=${ARG%%@*}; KEXPR=""; [[ "$ARG" == *@* ]] && KEXPR=${ARG#*@}
+      LOG="$OUT/tests_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-60).log"
+      if [ -n "$KEXPR" ]; then timeout -k 10 1100 python -m pytest $FILES -k "$KEXPR" -m gpu -x -q -s 2>&1 | tee "$LOG" | tail -40
+      else timeout -k 10 1100 python -m pytest $FILES -m gpu -x -q -s 2>&1 | tee "$LOG" | tail -40; fi ;;
     bench)  timeout -k 10 900 python bench.py --steps 20 --warmup 5 $ARG > "$OUT/bench_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40).json" 2> "$OUT/bench_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40).err" ; tail -c 600 "$OUT"/bench_*.json | tail -5 ;;
     benchq) timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loss-delta --no-kernel-events $ARG 2> "$OUT/benchq.err" | tee -a "$OUT/benchq.jsonl" | cut -c1-400 ;;
     prof)
