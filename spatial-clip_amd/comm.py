@@ -322,7 +322,10 @@ class FeatureGather:
     def __init__(self, device: torch.device):
         self.device = device
         self.cuda = device.type == "cuda"
-        self.stream = torch.cuda.Stream(device=device, priority=-1) if self.cuda else None
+        self.stream = None
+        if self.cuda:
+            from . import streams
+            self.stream = streams.comm_stream(device)          # shared with the sharded optimiser's weight gathers
         self._send, self._recv, self._done, self._src = {}, {}, {}, {}
         self._ids = (None, None)
         self.launched = 0          # number of collectives issued (tests)
@@ -518,7 +521,10 @@ class ShardedGradExchange:
             edges.pop(-2)
         self.buckets: List[Tuple[int, int]] = [(edges[i], edges[i + 1]) for i in range(len(edges) - 1)]
         self.cuda = self.flat.is_cuda
-        self.stream = torch.cuda.Stream(device=self.flat.device, priority=-1) if self.cuda else None
+        self.stream = None
+        if self.cuda:
+            from . import streams
+            self.stream = streams.comm_stream(self.flat.device)     # the step's one communication stream (streams.comm_stream)
         # order in which the next forward consumes the buckets: the second tower runs first and its parameters sit at the
         # END of the flat buffers (forward order of the vision tower, then the second tower, then logit_scale)
         first_second = min((s.offset for s in store.specs if not s.name.startswith("visual.")), default=0)
@@ -587,6 +593,8 @@ class ShardedGradExchange:
             return done
         if dist.get_backend() == "gloo":          # gloo has no reduce_scatter: all-reduce the bucket, the own piece is part of it
             return dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+        if os.environ.get("SC_SHARD_DEBUG_SKIP_RS") == "1" and self.W == 1:      # A/B probe (one rank: the collective is an identity)
+            return torch.cuda.Event()
         return dist.reduce_scatter_tensor(self.flat[a:b], self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self) -> None:
@@ -618,7 +626,7 @@ class ShardedGradExchange:
         self.ag_launched += 1
         if not self.cuda:
             dist.all_gather_into_tensor(st.master[lo:hi], st.master[a:b].clone())
-            st.refresh_range(lo, hi, self._copies[k], self._plans[k])
+            st.refresh_range(lo, hi, self._copies[k], self._plans[k], fresh=(a, b))
             return
         cur = torch.cuda.current_stream(self.flat.device)
         ready = torch.cuda.Event()
@@ -632,7 +640,7 @@ class ShardedGradExchange:
             else:
                 work = dist.all_gather_into_tensor(st.master[lo:hi], st.master[a:b], async_op=True)
                 work.wait()                         # the communication stream waits for RCCL's stream (no host block)
-            st.refresh_range(lo, hi, self._copies[k], self._plans[k])
+            st.refresh_range(lo, hi, self._copies[k], self._plans[k], fresh=(a, b))
             done = torch.cuda.Event()
             done.record(self.stream)
         st.pending.append((lo, hi, done))

@@ -76,7 +76,7 @@ class FusedAdamW:
             a, b = ex.piece(k)
             m, v = self.exp_avg[off[k]:off[k] + (b - a)], self.exp_avg_sq[off[k]:off[k] + (b - a)]
             ops.adamw_step(st.master[a:b], st.grad[a:b], m, v, b - a, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                           g["weight_decay"], self.step_count, grad_scale, clip, None)
+                           g["weight_decay"], self.step_count, grad_scale, clip, st.master_bf16[a:b])
             ex.gather_bucket(k)
         return self.norm_clip
 

@@ -368,10 +368,13 @@ class ParamStore:
                 out.append(c)
         return out
 
-    def refresh_range(self, lo: int, hi: int, copies, plan) -> None:
+    def refresh_range(self, lo: int, hi: int, copies, plan, fresh=None) -> None:
         """The same refresh for ONE range of the flat master buffer whose fp32 values have just arrived (all-gather of the
-        sharded optimiser): bf16 mirror of flat[lo:hi], then the derived copies of ``copies`` -- the weights that are complete
-        once this range is (the caller passes, per range, the weights that END in the latest-arriving range they touch)."""
-        n = hi - lo
-        ops.cast_pad_bf16(self.master[lo:hi].view(1, -1), self.master_bf16[lo:hi].view(1, -1), 1, n, n)
+        sharded optimiser): bf16 mirror of flat[lo:hi] -- except ``fresh`` = (a, b), the piece this rank's AdamW kernel has
+        just written itself, mirror included -- then the derived copies of ``copies``: the weights that are complete once
+        this range is (the caller passes, per range, the weights that END in the latest-arriving range they touch)."""
+        a, b = fresh if fresh is not None else (lo, lo)
+        for x, y in ((lo, a), (b, hi)):
+            if y > x:         # rows of 64 floats: the flat buffers are 64-float aligned everywhere
+                ops.cast_pad_bf16(self.master[x:y].view(-1, 64), self.master_bf16[x:y].view(-1, 64), (y - x) // 64, 64, 64)
         self._refresh_copies(copies, plan)

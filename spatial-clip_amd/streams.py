@@ -40,3 +40,20 @@ def consumer_streams():
     cur = torch.cuda.current_stream()
     s = _chain.get(torch.cuda.current_device())
     return [cur] if s is None or s == cur else [cur, s]
+
+
+_comm = {}
+
+
+def comm_stream(device=None):
+    """This device's ONE communication stream (high priority): the feature all-gathers of the step (comm.FeatureGather) and
+    the weight all-gathers / copy refreshes of the sharded optimiser (comm.ShardedGradExchange) share it.  Every extra HIP
+    stream is another candidate for one of the few hardware queues of the device (4 by default): with a fifth busy stream
+    the low-priority weight-gradient stream ended up multiplexed with the chain and the overlapped backward ran 2.3 ms
+    SLOWER (measured, one rank, profiles/r05_grad_exchange_one_rank.txt) -- streams are created per ROLE, not per object."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _comm.get(key)
+    if s is None:
+        s = _comm[key] = torch.cuda.Stream(device=dev, priority=-1)
+    return s

@@ -224,7 +224,8 @@ class _FakeStore:
     def _transpose_plan(self, copies):
         return None
 
-    def refresh_range(self, lo, hi, copies, plan):
+    def refresh_range(self, lo, hi, copies, plan, fresh=None):
+        assert fresh is not None and lo <= fresh[0] < fresh[1] <= hi
         self.refreshed.append((lo, hi))
 
 

@@ -9,6 +9,7 @@
 #   prof[:single|side]                           rocprofv3 --kernel-trace --stats of the bench command (SC_OVERLAP=0 / default)
 #   pmc                                          the FETCH_SIZE / WRITE_SIZE / MFMA PMC passes + summaries
 #   py:<script and args>                         python <script ...> (tools/*.py micro-benchmarks)
+#   env:VAR=VALUE / unset:VAR                    environment of the steps that follow (A/B switches)
 set -e -o pipefail
 TAG=$1; shift
 OUT=gpurun_out/$TAG
@@ -47,6 +48,8 @@ for STEP in "$@"; do
       python tools/pmc_summary.py $(find $OUT/pmc_f -name "f_counter_collection.csv") $(find $OUT/pmc_w -name "w_counter_collection.csv") $OUT/pmc_traffic_summary.json > $OUT/pmc_traffic.txt 2>&1; head -14 $OUT/pmc_traffic.txt
       python tools/pmc_generic.py $OUT/pmc_mfma_summary.json "$OUT/pmc_m/**/m_counter_collection.csv" > $OUT/pmc_mfma.txt 2>&1; head -14 $OUT/pmc_mfma.txt
       find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
+    env)    export "$ARG"; echo "exported $ARG" ;;
+    unset)  unset "$ARG"; echo "unset $ARG" ;;
     py)     timeout -k 10 900 python $ARG 2>&1 | tee "$OUT/py_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-60).log" | tail -60 ;;
     *) echo "unknown step $KIND"; exit 2 ;;
   esac
