@@ -539,6 +539,12 @@ extern "C" int sc_attn_bwd(const void* qkv, const void* out, const void* dout, c
         SC_LAUNCH_CHECK();
         return 0;
     }
+    // round 5: 225..257 tokens (ViT-L/14): the ring design with eight key waves and no helper wave
+    const bool ring8_on = !(getenv("SC_ATTN_BWD4") && getenv("SC_ATTN_BWD4")[0] == '0');
+    if (ring8_on && sc_attn_bwd_ring8(qkv, out, dout, lse, delta, dqkv, B, L, Lq, H, dh, causal, st)) {
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     const bool single_on = !(getenv("SC_ATTN_BWD1") && getenv("SC_ATTN_BWD1")[0] == '0');
     if (single_on && sc_attn_bwd_single_pass(qkv, out, dout, lse, delta, dqkv, B, L, Lq, H, dh, causal, st)) {
         SC_LAUNCH_CHECK();

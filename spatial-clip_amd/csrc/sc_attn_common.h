@@ -22,6 +22,11 @@ int sc_attn_bwd_single_pass(const void* qkv, const void* out, const void* dout, 
 int sc_attn_bwd_ring(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
                      int L, int Lq, int H, int dh, int causal, hipStream_t st);
 
+// sc_attention_bwd4.hip (round 5): the ring design for 224 < L <= 257 (eight key waves, no helper wave, the 257th key as
+// rank-one terms in the reducers); 1 = launched
+int sc_attn_bwd_ring8(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+                      int L, int Lq, int H, int dh, int causal, hipStream_t st);
+
 // sc_attention_bwd2.hip: persistent two-pass backward with loader waves; 1 = launched, 0 = shape out of range
 int sc_attn_bwd_persistent(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            int B, int L, int Lq, int H, int dh, int causal, hipStream_t st);

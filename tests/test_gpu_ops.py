@@ -144,6 +144,44 @@ def test_attention_bwd_paths_walk_many_heads(B, L, H, causal, path, monkeypatch)
     torch.testing.assert_close(delta1.cpu(), want_delta, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("B,L,H", [(24, 257, 16), (300, 257, 1), (40, 256, 3), (70, 225, 5), (33, 240, 8), (3, 257, 2),
+                                   (260, 250, 1)])
+def test_attention_bwd_ring8_for_225_to_257_tokens(B, L, H, monkeypatch):
+    """Round 5 (sc_attention_bwd4.hip): the dS-ring backward with eight key waves and no helper wave, for ViT-L/14's 257
+    tokens (the 257th key enters as rank-one terms computed by the reducers) and for 225..256 tokens.  More heads than CUs so
+    that a workgroup walks several heads; against autograd, bit-identical across two launches, and against the
+    one-workgroup-per-head kernel (SC_ATTN_BWD4=0) to bf16 rounding; delta = rowsum(dO O) is an output too."""
+    ops = _ops()
+    dh = 64
+    d = H * dh
+    g = torch.Generator().manual_seed(B * 5 + L)
+    qkv = bf(torch.randn(B * L, 3 * d, generator=g))
+    dout = bf(torch.randn(B * L, d, generator=g))
+    x = qkv.float().requires_grad_(True)
+    o_ref, _ = ref_attn(x, B, L, H, dh, False)
+    o_ref.backward(dout.float())
+    qd, gd = qkv.cuda(), dout.cuda()
+    out, lse = ops.attn_fwd(qd, B, L, H, dh, False)
+    monkeypatch.setenv("SC_ATTN_BWD4", "1")
+    dq1 = torch.full((B * L, 3 * d), 7.0, dtype=torch.bfloat16, device="cuda")
+    delta1 = torch.full((B, H, L), 7.0, device="cuda")
+    ops.attn_bwd(qd, out, gd, lse, B, L, H, dh, False, dqkv=dq1, delta=delta1)
+    dq2 = torch.full_like(dq1, 3.0)
+    ops.attn_bwd(qd, out, gd, lse, B, L, H, dh, False, dqkv=dq2)
+    torch.cuda.synchronize()
+    assert torch.equal(dq1, dq2)
+    torch.testing.assert_close(dq1.float().cpu(), x.grad, atol=4e-2, rtol=4e-2)
+    want_delta = (dout.float() * out.float().cpu()).view(B, L, H, dh).sum(-1).permute(0, 2, 1)
+    torch.testing.assert_close(delta1.cpu(), want_delta, atol=2e-2, rtol=2e-2)
+    monkeypatch.setenv("SC_ATTN_BWD4", "0")
+    dq3 = torch.full_like(dq1, 5.0)
+    ops.attn_bwd(qd, out, gd, lse, B, L, H, dh, False, dqkv=dq3)
+    torch.testing.assert_close(dq1.float().cpu(), dq3.float().cpu(), atol=3e-2, rtol=3e-2)
+    # the last token (row 256 at L = 257) is the stray key: its dK / dV rows on their own
+    last = slice(L - 1, None, L)
+    torch.testing.assert_close(dq1.float().cpu()[last], x.grad[last], atol=4e-2, rtol=4e-2)
+
+
 @pytest.mark.parametrize("rows,d", [(50, 768), (197 * 2, 192), (33, 64), (7, 1024)])
 def test_layernorm_fwd_bwd(rows, d):
     ops = _ops()
