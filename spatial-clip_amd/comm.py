@@ -27,6 +27,7 @@ All functions are device-agnostic (CUDA/HIP or CPU tensors) and degrade to no-op
 from __future__ import annotations
 
 import os
+import sys
 from typing import List, Optional, Tuple
 
 import torch
@@ -63,9 +64,10 @@ def describe() -> dict:
     """Facts about the live group for the bench's stderr / JSON line: backend, ranks the RCCL communicator spans (0 = no RCCL
     communicator exists: plain single-process run or gloo), RCCL version, route, gradient-exchange mode."""
     info = {"backend": None, "world_size": 1, "rccl_ranks": 0, "rccl_version": None, "route": route(),
-            "grad_exchange": grad_exchange_mode()}
+            "grad_exchange": grad_exchange_mode(), "inplace_collectives_verified": None}
     if dist.is_available() and dist.is_initialized():
         info["backend"] = dist.get_backend()
+        info["inplace_collectives_verified"] = describe_inplace_check()
         info["world_size"] = dist.get_world_size()
         if info["backend"] == "nccl":
             # a SUM all-reduce of ones over the communicator the step uses: the number of ranks RCCL itself reaches
@@ -77,6 +79,14 @@ def describe() -> dict:
             except Exception:
                 info["rccl_version"] = "unknown"
     return info
+
+
+def describe_inplace_check() -> Optional[bool]:
+    """Verdict of ``inplace_collectives_verified`` on the live group (None: not run -- no group, or the all-reduce route was asked for)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    checks = [v for (bk, _), v in _INPLACE_CHECK.items() if bk == dist.get_backend()]
+    return all(checks) if checks else None
 
 
 def grad_exchange_mode() -> str:
@@ -208,6 +218,7 @@ def shutdown() -> None:
     if _native is not None:
         _native.destroy()
         _native = None
+    _INPLACE_CHECK.clear()
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
@@ -663,11 +674,66 @@ class ShardedGradExchange:
             off += b - a
 
 
+_INPLACE_CHECK: dict = {}
+
+
+def inplace_collectives_verified(device) -> bool:
+    """Start-up check of the two IN-PLACE collectives the sharded exchange relies on (reduce-scatter whose output is the rank's
+    piece of its input; all-gather whose input is the rank's piece of its output), on a small scratch buffer against a plain
+    SUM all-reduce.  Collective: every rank calls it; the verdict is the MIN over ranks, so all ranks take the same route.
+    Runs once per process group and device; the result is in ``describe()``."""
+    key = (dist.get_backend(), str(device))
+    if key in _INPLACE_CHECK:
+        return _INPLACE_CHECK[key]
+    rank, W = world()
+    n = 256 * W
+    base = (torch.arange(n, dtype=torch.float32, device=device) % 97) * 0.25
+    mine = base * float(rank + 1) + float(rank)
+    want = mine.clone()
+    dist.all_reduce(want, op=dist.ReduceOp.SUM)
+    c = n // W
+    a, b = rank * c, (rank + 1) * c
+    ok = True
+    try:
+        buf = mine.clone()
+        if _native is not None and buf.is_cuda:
+            cur = torch.cuda.current_stream(buf.device)
+            _native.reduce_scatter(buf, buf[a:b], cur)
+        elif dist.get_backend() == "gloo":
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce_scatter_tensor(buf[a:b], buf, op=dist.ReduceOp.SUM)
+        ok = ok and bool(torch.equal(buf[a:b], want[a:b]))
+        buf = torch.full_like(mine, -1.0)
+        buf[a:b] = want[a:b]
+        if _native is not None and buf.is_cuda:
+            _native.all_gather(buf[a:b], buf, torch.cuda.current_stream(buf.device))
+        elif dist.get_backend() == "gloo":
+            dist.all_gather_into_tensor(buf, buf[a:b].clone())
+        else:
+            dist.all_gather_into_tensor(buf, buf[a:b])
+        ok = ok and bool(torch.equal(buf, want))
+    except RuntimeError as e:               # a backend that refuses aliased buffers says so here, not in the first training step
+        sys.stderr.write(f"[spatial_clip_amd.comm] rank {rank}: in-place collective refused: {e}\n")
+        ok = False
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    _INPLACE_CHECK[key] = bool(flag.item() > 0.5)
+    return _INPLACE_CHECK[key]
+
+
 def make_grad_exchange(store, bucket_floats: int = 16 * 1024 * 1024):
     """The gradient exchange of this process group: ``ShardedGradExchange`` (default) or the rounds-1-4
-    ``GradBucketReducer`` (SC_GRAD_EXCHANGE=allreduce); None without a group."""
+    ``GradBucketReducer`` (SC_GRAD_EXCHANGE=allreduce); None without a group.  The sharded route is taken only after its two
+    in-place collectives have reproduced a plain all-reduce on this group (``inplace_collectives_verified``); otherwise every
+    rank says so on stderr and takes the all-reduce route -- same weights, the reference's DDP shape."""
     if not is_dist():
         return None
     if grad_exchange_mode() == "allreduce":
+        return GradBucketReducer(store.grad, bucket_floats)
+    if not inplace_collectives_verified(store.grad.device):
+        sys.stderr.write("[spatial_clip_amd.comm] in-place reduce-scatter / all-gather did not reproduce the all-reduce on this "
+                         "process group: gradient exchange falls back to bucketed all-reduce + replicated AdamW\n")
+        os.environ["SC_GRAD_EXCHANGE"] = "allreduce"
         return GradBucketReducer(store.grad, bucket_floats)
     return ShardedGradExchange(store, bucket_floats)

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16* __restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool STRAY = (NBQ == 9);
     constexpr int DH = B4DH, KS = DH / 32, DT = DH / 16, NW = B4NW, RING = B4RING;
-    constexpr int ROWS = STRAY ? 272 : 256;             // rows of an image (8-row DMA pieces)
+    constexpr int ROWS = STRAY ? 264 : 256;             // rows of an image (8-row DMA pieces; row 256 is the only real one of the last)
     constexpr int IMG = ROWS * DH * 2;                  // Q and dO images
     constexpr int KIMG = 256 * DH * 2;                  // K image: keys 0..255 (the stray key's row travels on its own)
     constexpr int SLOT = NW * 2048;                     // one ring slot: NW dS tiles [key 32][q 32] bf16
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16* __restrict__
     float* pR = stats0 + 4 * ROWS;                                       // [NW][2: dV, dK][64] stray partial sums
     char* vR0 = reinterpret_cast<char*>(pR + NW * 128);                 // [2 heads][V row 256 | K row 256] (64 bf16 each)
     float* scr = reinterpret_cast<float*>(vR0 + 512);                   // [NW][64] dS of the stray key for the wave's query block(s)
-    const unsigned ctr0 = (unsigned)(uintptr_t)(lptr_t)smem + 2 * IMG + KIMG + RING * SLOT + 4 * ROWS * 4 + NW * 128 * 4 + 512 + NW * 64 * 4;
+    float* qR = scr + NW * 64;                                           // [NW][64] query row 256: the waves' partial sums of its dQ
+    const unsigned ctr0 = (unsigned)(uintptr_t)(lptr_t)smem + 2 * IMG + KIMG + RING * SLOT + 4 * ROWS * 4 + NW * 128 * 4 + 512 +
+                          NW * 64 * 4 + (STRAY ? NW * 64 * 4 : 0);
     // ready[j] at ctr0 + 4 j, done[j] at ctr0 + 4 NBQ + 4 j, kready at ctr0 + 8 NBQ
     const unsigned kready = ctr0 + 8 * NBQ;             // += 1 by every wave once its pieces of the head's K image have landed
     const unsigned psum = kready + 4;                   // += 1 by wave 0 once it has added up the head's stray partial sums
@@ -103,10 +105,11 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16* __restrict__
             dma16(src0 + (long long)rowc * stride + (pch ^ Img<DH>::swz(row)) * 8, img + pp * 1024);
         }
     };
-    // Q and dO rows of query block bq of `head` (block 8: the two pieces that hold rows 256..271)
+    // Q and dO rows of query block bq of `head` (block 8: the one piece that holds rows 256..263; the fragment reads of rows
+    // 264..287 land in the image behind -- finite values that only ever meet masked probabilities)
     auto refill = [&](int head, int bq) {
         const int b = head / H, h = head % H;
-        const int first = 4 * bq, last = (STRAY && bq == 8) ? 4 * bq + 2 : 4 * bq + 4;
+        const int first = 4 * bq, last = (STRAY && bq == 8) ? 4 * bq + 1 : 4 * bq + 4;
         dma_rows(qkv + (long long)b * L * rs + h * DH, rs, Qimg, first, last);
         dma_rows(dout + (long long)b * L * d + h * DH, d, Gimg, first, last);
     };
@@ -220,8 +223,8 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16* __restrict__
 
     // ---------------------------------------------------------------------- prologue: everything of the first head
     if (t < 2 * NBQ + 2) asm volatile("ds_write_b32 %0, %1" ::"v"(ctr0 + 4 * t), "v"(0u) : "memory");
-    if (STRAY && t < 60) {                              // rows 257..271 of both buffers are never valid queries
-        const int bufi = t / 30, which = (t % 30) / 15, r = 257 + t % 15;
+    if (STRAY && t < 28) {                              // rows 257..263 of both buffers are never valid queries
+        const int bufi = t / 14, which = (t % 14) / 7, r = 257 + t % 7;
         stats0[bufi * 2 * ROWS + which * ROWS + r] = 0.f;
     }
     int head = blockIdx.x;
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16* __restrict__
             if (STRAY) {
                 // the stray key's rank-one term: dQ[q][:] += dS_q k_256, dS_q from this wave's pre-pass (stray_block), lane =
                 // query li of tile a, registers = features 16 dt + 4 lg + r
-                const float* sd = (bq == 8) ? sds + 32 : sds;
+                const float* sd = sds;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const bf16x4 kr = *reinterpret_cast<const bf16x4*>(kR + (16 * dt + 4 * lg) * 2);
@@ -462,6 +465,20 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16* __restrict__
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // rows of block j read, dS tile written
             if (lane == 0) lds_bump(ctr0 + 4 * j);                        // ready[j]
+            if (STRAY && j == NBQ - 1) {
+                // The single query row 256 does not go through the ring: its dQ is a sum over ALL keys, and this wave's share
+                // (its 32 keys) is one MFMA per 16 features on its own dS tile, read back transposed, against its own rows of
+                // the K image; the eight partial sums are added in wave order behind the end-of-head barrier.
+                const int ln = fresh_lane(), li2 = ln & 15, lg2 = ln >> 4;
+                const bf16x8 dst0 = frag_tr_ds(tile, 0, li2, lg2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const f32x4 part = sc_mfma16(frag_tr<DH>(Kimg, kb, dt * 16, li2, lg2), dst0, z);
+                    if (li2 == 0) *reinterpret_cast<f32x4*>(qR + wave * 64 + 16 * dt + 4 * lg2) = part;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             TR4(1 + j);
             // this wave reduces block `wave` one step behind (the other key waves are through it by then)
 #ifndef B4_T_NO_REDUCE
@@ -474,9 +491,9 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16* __restrict__
         // into their registers), in front of the work that is left, whose time hides the loads' latency
         B4Next x;
         if (!STRAY && next < nheads) issue_next(next, x, kf, vf);      // (L = 257: no registers to spare beside the last reduction)
-        // the block that has no later step: NBQ = 9 -> block 8 (one tile, the single row 256) by wave 0; NBQ = 8 -> block 7 by wave 7
-        if (STRAY) { if (wave == 0) reduce(8, 1); }
-        else if (wave == NW - 1) reduce(NW - 1, 2);
+        // the block that has no later step: NBQ = 8 -> block 7 by wave 7 (NBQ = 9: wave 7 reduced it at step 8, and the single
+        // row of "block" 8 is not a ring block: see the partial sums above)
+        if (!STRAY && wave == NW - 1) reduce(NW - 1, 2);
         if (next < nheads) {    // the last two blocks' rows (waves that reduce nothing here)
             if (wave == 4) { lds_wait_ge(ctr0 + 4 * (NBQ - 2), (unsigned)NW * u1); refill(next, NBQ - 2); }
             if (wave == 3) { lds_wait_ge(ctr0 + 4 * (NBQ - 1), (unsigned)NW * u1); refill(next, NBQ - 1); }
@@ -508,21 +525,28 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(const bf16* __restrict__
         if (next < nheads) k_image(next);                  // the K image is free; not waited for: the next head's reducers look at `kready`
         if (STRAY && wave == 0) {                          // row 256 of dV / dK: the waves' partial sums in wave order
             const int ln = fresh_lane();
-            float sv = 0.f, sk = 0.f;
+            float sv = 0.f, sk = 0.f, sq = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 sv += pR[w * 128 + ln];
                 sk += pR[w * 128 + 64 + ln];
+                sq += qR[w * 64 + ln];
             }
+            // ... and dQ of query row 256: the partial sums over keys 0..255 plus the stray key's own term dS(256, 256) k_256
+            // (wave 0's pre-pass left that dS at sds[32])
+            sq = fmaf(sds[32], (float)reinterpret_cast<const bf16*>(kR)[ln], sq);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (ln == 0) lds_bump(psum);                   // the waves may zero their partial sums for the next head
             sk *= scale;
-            const float sv1 = __shfl_down(sv, 1, 64), sk1 = __shfl_down(sk, 1, 64);
+            sq *= scale;
+            const float sv1 = __shfl_down(sv, 1, 64), sk1 = __shfl_down(sk, 1, 64), sq1 = __shfl_down(sq, 1, 64);
             if ((ln & 1) == 0) {
-                union { unsigned u; bf16 hh[2]; } pv, pk;
+                union { unsigned u; bf16 hh[2]; } pv, pk, pq;
                 pv.hh[0] = (bf16)sv; pv.hh[1] = (bf16)sv1;
                 pk.hh[0] = (bf16)sk; pk.hh[1] = (bf16)sk1;
+                pq.hh[0] = (bf16)sq; pq.hh[1] = (bf16)sq1;
                 bf16* row = dqkv + ((long long)b * L + 256) * rs + h * DH + ln;
+                *reinterpret_cast<unsigned*>(row) = pq.u;
                 *reinterpret_cast<unsigned*>(row + d) = pk.u;
                 *reinterpret_cast<unsigned*>(row + 2 * d) = pv.u;
             }
@@ -551,9 +575,10 @@ int sc_attn_bwd_ring8(const void* qkv, const void* out, const void* dout, const 
                       int L, int Lq, int H, int dh, int causal, hipStream_t st) {
     if (dh != B4DH || L <= 224 || L > 257 || Lq != L || causal) return 0;
     const int NBQ = L > 256 ? 9 : 8;
-    const int rows = NBQ == 9 ? 272 : 256;
+    const int rows = NBQ == 9 ? 264 : 256;
     const size_t lds = (size_t)2 * rows * dh * 2 + (size_t)256 * dh * 2 + (size_t)B4RING * B4NW * 2048 + (size_t)4 * rows * 4 +
-                       (size_t)B4NW * 128 * 4 + 512 + (size_t)B4NW * 64 * 4 + (size_t)(2 * NBQ + 2) * 4 + 56;
+                       (size_t)B4NW * 128 * 4 + 512 + (size_t)B4NW * 64 * 4 + (NBQ == 9 ? (size_t)B4NW * 64 * 4 : 0) +
+                       (size_t)(2 * NBQ + 2) * 4 + 56;
     const long long dqb = (long long)B * L * 3 * H * dh * 2;
     if (dqb >= 0xFFFFFFF0ll) return 0;
     if (lds > 160 * 1024) return 0;

@@ -2,6 +2,7 @@
 // the next GEMM), L2-normalise fwd/bwd of the embedding heads, column sums (bias grads), casts.
 // One 64-lane wave owns one row; every access is a 16-byte (fp32x4) or 8-byte (bf16x4) vector.
 #include "sc_common.h"
+#include <stdlib.h>
 #include "sc_kernels.h"
 #include "sc_gemm_common.h"   // sc_gelu_fast: the GELU of the GEMM epilogues
 
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // GIN: the incoming gradient is the bf16 stream `gin` for every row (accumulate > 0): its loads are issued together with
 // dy / x instead of behind the two wave reductions (one exposed memory round trip per row less; gamma is re-read per row from
 // L1 so that the kernel stays at 128 VGPRs = 4 waves per SIMD).
-template <int NV, bool Q8, bool XB = false, bool GIN = false>
+template <int NV, bool Q8, bool XB = false, bool GIN = false, bool LEAN = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      float* __restrict__ partial, int rows, int d, int accumulate,
                                                      unsigned char* __restrict__ d8, long long ldd8,
                                                      float* __restrict__ scale_inv, const bf16* __restrict__ gin = nullptr,
-                                                     long long ldgin = 0, int write_f32 = 1, const LnT8 t8 = LnT8()) {
+                                                     long long ldgin = 0, int write_f32 = 1, const LnT8 t8 = LnT8(),
+                                                     int nominal_blocks = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -166,6 +168,69 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         const bf16* dyr = dy + (long long)row * lddy;
         const float* xr = x + (long long)row * ldx;
         const bf16* xrb = reinterpret_cast<const bf16*>(x) + (long long)row * ldx;
+        if constexpr (LEAN) {
+            // Wide rows (d = 1024: NV = 4) with bf16 rows and a bf16 gradient stream: the row's three inputs stay in their
+            // packed bf16 form (24 registers instead of the 40 of g / x_hat in fp32) and dy * gamma, x_hat are formed twice,
+            // gamma re-read from L1 -- 140 -> under 128 VGPRs, the fourth wave per SIMD (same arithmetic, same order).
+            static_assert(GIN && XB && !Q8, "lean row body: bf16 rows, bf16 gradient stream, no e4m3 copy");
+            bf16x4 dyp[NV], xp[NV], gp[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = i * 64 + lane;
+                if (e < nv) {
+                    gp[i] = *reinterpret_cast<const bf16x4*>(gin + (long long)row * ldgin + e * 4);
+                    dyp[i] = *reinterpret_cast<const bf16x4*>(dyr + e * 4);
+                    xp[i] = *reinterpret_cast<const bf16x4*>(xrb + e * 4);
+                }
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = i * 64 + lane;
+                if (e < nv) {
+                    const f32x4 gmv = ld4(gamma + e * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float dyv = (float)dyp[i][c];
+                        const float xhv = __fmul_rn((float)xp[i][c] - mu, rs);      // (rounded products: the second pass must
+                        const float gv = __fmul_rn(dyv, gmv[c]);                     //  form the very same values, uncontracted)
+                        s1 += gv;
+                        s2 += gv * xhv;
+                        ag[i][c] += dyv * xhv;
+                        ab[i][c] += dyv;
+                    }
+                }
+            }
+            s1 = sc_wave_sum(s1) / (float)d;
+            s2 = sc_wave_sum(s2) / (float)d;
+            float* dr = dres + (long long)row * lddres;
+            bf16* db = dres_bf ? dres_bf + (long long)row * lddbf : nullptr;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {       // opaque to the optimiser: otherwise it keeps the fp32 conversions of the first pass alive
+                union { bf16x4 v; u32x2 u; } a, b;
+                a.v = dyp[i]; b.v = xp[i];
+                asm volatile("" : "+v"(a.u), "+v"(b.u));
+                dyp[i] = a.v; xp[i] = b.v;
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = i * 64 + lane;
+                if (e < nv) {
+                    const f32x4 gmv = ld4(gamma + e * 4);
+                    f32x4 o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float xhv = __fmul_rn((float)xp[i][c] - mu, rs);
+                        const float gv = __fmul_rn((float)dyp[i][c], gmv[c]);
+                        o[c] = (float)gp[i][c] + rs * (gv - s1 - xhv * s2);
+                        ac[i][c] += o[c];
+                    }
+                    if (write_f32) st4(dr + e * 4, o);
+                    if (db) stbf4(db + e * 4, o);
+                }
+            }
+            continue;
+        }
         f32x4 g[NV], xh[NV];
         bf16x4 gin_raw[GIN ? NV : 1];
         float s1 = 0.f, s2 = 0.f;
@@ -244,21 +309,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             }
         }
     }
-    // block reduce of the 3 column vectors: smem[wave][3][d]
+    // block reduce of the 3 column vectors: waves 1..3 through smem[wave - 1][3][d], wave 0 adds them to its registers in wave
+    // order (w0 + w1 + w2 + w3) -- 36 KiB at d = 1024, so that four blocks fit a CU's LDS
     float* sm = reinterpret_cast<float*>(smem);
+    if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int e = i * 64 + lane;
-        if (e < nv) {
-            st4(sm + (wave * 3 + 0) * d + e * 4, ag[i]);
-            st4(sm + (wave * 3 + 1) * d + e * 4, ab[i]);
-            st4(sm + (wave * 3 + 2) * d + e * 4, ac[i]);
+        for (int i = 0; i < NV; ++i) {
+            const int e = i * 64 + lane;
+            if (e < nv) {
+                st4(sm + ((wave - 1) * 3 + 0) * d + e * 4, ag[i]);
+                st4(sm + ((wave - 1) * 3 + 1) * d + e * 4, ab[i]);
+                st4(sm + ((wave - 1) * 3 + 2) * d + e * 4, ac[i]);
+            }
         }
     }
     __syncthreads();
     float* pout = partial + (long long)blockIdx.x * 3 * d;
-    for (int e = threadIdx.x; e < 3 * d; e += 256) {
-        pout[e] = sm[e] + sm[3 * d + e] + sm[6 * d + e] + sm[9 * d + e];
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = i * 64 + lane;
+            if (e < nv) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    ag[i] += ld4(sm + (w * 3 + 0) * d + e * 4);
+                    ab[i] += ld4(sm + (w * 3 + 1) * d + e * 4);
+                    ac[i] += ld4(sm + (w * 3 + 2) * d + e * 4);
+                }
+                st4(pout + 0 * d + e * 4, ag[i]);
+                st4(pout + 1 * d + e * 4, ab[i]);
+                st4(pout + 2 * d + e * 4, ac[i]);
+            }
+        }
+    }
+    // the finalising pass sums `nominal_blocks` slots (a function of the row count alone: it may run from another entry point,
+    // on another stream); a grid capped at the resident blocks leaves the others as zeros
+    for (int sl = blockIdx.x + gridDim.x; sl < nominal_blocks; sl += gridDim.x) {
+        float* z = partial + (long long)sl * 3 * d;
+        for (int e = threadIdx.x; e < 3 * d; e += 256) z[e] = 0.f;
     }
 }
 
@@ -595,6 +683,30 @@ extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
     return (long long)nblk * 3 * d;
 }
 
+// The row loop of the LayerNorm kernels is persistent (a wave walks rows with a grid stride), so a grid larger than what is
+// resident at once only adds a second, thinly occupied round: at d = 1024 the backward needs 140 VGPRs = 3 waves per SIMD and
+// 48 KiB of LDS = 3 blocks per CU, i.e. 768 of the 1024 blocks launched ran first and the other 256 afterwards with one block
+// per CU (ViT-L/14: 190 us for 540 MB).  The grid is capped at the kernel's resident blocks (occupancy query, once per kernel
+// and LDS size).
+static int ln_resident_blocks(const void* fn, size_t lds, int nblk) {
+#ifdef SC_LN_GRID_UNCAPPED
+    return nblk;
+#else
+    struct Slot { const void* fn; size_t lds; int blocks; };
+    static Slot slots[64];
+    static int nslots = 0;
+    for (int i = 0; i < nslots; ++i)
+        if (slots[i].fn == fn && slots[i].lds == lds) return nblk < slots[i].blocks ? nblk : slots[i].blocks;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return nblk;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu <= 0) return nblk;
+    const int blocks = per_cu * (p.multiProcessorCount > 0 ? p.multiProcessorCount : 256);
+    if (nslots < 64) { slots[nslots].fn = fn; slots[nslots].lds = lds; slots[nslots].blocks = blocks; ++nslots; }
+    return nblk < blocks ? nblk : blocks;
+#endif
+}
+
 static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long long ldx, const float* mean,
                          const float* rstd, const float* gamma, float* dres, long long lddres, void* dres_bf16,
                          long long lddbf, int accumulate, float* dgamma, float* dbeta, float* colsum, float* ws, int rows,
@@ -607,7 +719,7 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
              "sc_layernorm_bwd_q8: fp8 output needs scale_inv and a row stride that is a multiple of 4 (ldd8=%lld)", ldd8);
     int nblk = (rows + 3) / 4;
     if (nblk > 1024) nblk = 1024;
-    const size_t lds = (size_t)4 * 3 * d * sizeof(float);
+    const size_t lds = (size_t)3 * 3 * d * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int nvv = (d / 4 + 63) / 64;
 #define SC_LN_BWD_QG(NV, Q, G, I)                                                                                       \
@@ -615,10 +727,11 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
         if (lds > 48 * 1024)                                                                                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, Q, G, I>),                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        ln_bwd_kernel<NV, Q, G, I><<<nblk, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres,      \
+        const int grid = ln_resident_blocks(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, Q, G, I>), lds, nblk);     \
+        ln_bwd_kernel<NV, Q, G, I><<<grid, 256, lds, st>>>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres,      \
                                                            lddres, (bf16*)dres_bf16, lddbf, ws, rows, d, accumulate,    \
                                                            (unsigned char*)d8, ldd8, scale_inv, (const bf16*)gin,       \
-                                                           ldgin, write_f32, t8);                                       \
+                                                           ldgin, write_f32, t8, nblk);                                 \
     } while (0)
 #define SC_LN_BWD_Q(NV, Q, G)                                                                                           \
     do {                                                                                                                \
@@ -629,8 +742,26 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
         if (xb) { if (d8) SC_LN_BWD_Q(NV, true, true); else SC_LN_BWD_Q(NV, false, true); }                             \
         else { if (d8) SC_LN_BWD_Q(NV, true, false); else SC_LN_BWD_Q(NV, false, false); }                              \
     } while (0)
-    if (nvv <= 1) SC_LN_BWD(1); else if (nvv == 2) SC_LN_BWD(2); else if (nvv == 3) SC_LN_BWD(3);
+    // lean row body (bf16 rows + bf16 gradient stream, no e4m3 copies): d = 1024 by default; SC_LN_BWD_LEAN=0 off, =3 also d = 768
+    const char* lean_env = getenv("SC_LN_BWD_LEAN");      // read per call: the tests run both bodies in one process
+    const int lean_mode = lean_env ? atoi(lean_env) : 4;
+    const bool lean_ok = xb && d8 == nullptr && gin != nullptr && accumulate > 0 && lean_mode != 0;
+#define SC_LN_BWD_LEAN(NV)                                                                                              \
+    do {                                                                                                                \
+        if (lds > 48 * 1024)                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, false, true, true, true>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        const int grid = ln_resident_blocks(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, false, true, true, true>), \
+                                            lds, nblk);                                                                 \
+        ln_bwd_kernel<NV, false, true, true, true><<<grid, 256, lds, st>>>(                                             \
+            (const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, (bf16*)dres_bf16, lddbf, ws, rows, d,       \
+            accumulate, nullptr, 0, nullptr, (const bf16*)gin, ldgin, write_f32, t8, nblk);                             \
+    } while (0)
+    if (lean_ok && nvv == 4) SC_LN_BWD_LEAN(4);
+    else if (lean_ok && nvv == 3 && lean_mode == 3) SC_LN_BWD_LEAN(3);
+    else if (nvv <= 1) SC_LN_BWD(1); else if (nvv == 2) SC_LN_BWD(2); else if (nvv == 3) SC_LN_BWD(3);
     else if (nvv == 4) SC_LN_BWD(4); else SC_LN_BWD(8);
+#undef SC_LN_BWD_LEAN
 #undef SC_LN_BWD
 #undef SC_LN_BWD_Q
 #undef SC_LN_BWD_QG

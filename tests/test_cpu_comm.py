@@ -276,6 +276,15 @@ def _sharded_worker(rank, world, port, ret):
     back = torch.zeros_like(shard)
     ex.scatter_moments(full, back)
     assert torch.equal(back, shard)
+    # start-up check of the in-place collectives (what make_grad_exchange runs before it takes the sharded route), and the
+    # route a group takes when the check fails: bucketed all-reduce, on every rank
+    assert comm.inplace_collectives_verified(torch.device("cpu")) is True
+    assert isinstance(comm.make_grad_exchange(st, bucket_floats=1024), comm.ShardedGradExchange)
+    assert comm.describe()["inplace_collectives_verified"] is True
+    for key in list(comm._INPLACE_CHECK):
+        comm._INPLACE_CHECK[key] = False
+    assert isinstance(comm.make_grad_exchange(st, bucket_floats=1024), comm.GradBucketReducer)
+    assert comm.grad_exchange_mode() == "allreduce"
     ret[rank] = {"master": st.master.numpy().copy(), "full": full.numpy().copy(), "stats": dict(comm.STATS)}
     dist.destroy_process_group()
 

@@ -246,6 +246,10 @@ def _rccl_worker(rank, world, port, force, ret, native=False, exchange="sharded"
     assert comm.native() is None
 
 
+def nat_info(res):
+    return res["native"]["info"]["inplace_collectives_verified"]
+
+
 def test_rccl_one_rank_group_runs_every_collective_and_changes_nothing():
     mp.set_start_method("spawn", force=True)
     with mp.Manager() as mgr:
@@ -264,6 +268,7 @@ def test_rccl_one_rank_group_runs_every_collective_and_changes_nothing():
     assert st["reduce_scatter(gradient bucket)"][0] >= 9 and st["all_gather(weights bucket)"][0] == st["reduce_scatter(gradient bucket)"][0]
     assert "all_reduce(gradient bucket)" not in st
     assert res[True]["info"]["backend"] == "nccl" and res[True]["info"]["rccl_ranks"] == 1 and res[True]["info"]["grad_exchange"] == "sharded"
+    assert res[True]["info"]["inplace_collectives_verified"] is True and nat_info(res) is True
     ar = res["allreduce"]
     assert ar["stats"]["all_reduce(gradient bucket)"][0] >= 3 and "all_gather(weights bucket)" not in ar["stats"]
     assert ar["loss"] == res[False]["loss"] and torch.equal(ar["w"], res[False]["w"])

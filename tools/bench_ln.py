@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""LayerNorm forward / backward kernels alone at the headline shape (50 432 rows x 768): time and bytes per launch."""
+"""LayerNorm forward / backward kernels alone: time and bytes per launch.  Default = the headline shape (50 432 rows x 768);
+``python tools/bench_ln.py 65792 1024`` = ViT-L/14 at 256 tiles of 257 tokens."""
 import os
 import sys
 
@@ -9,7 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import spatial_clip_amd  # noqa: F401
 from spatial_clip_amd import ops
 
-M, d = 256 * 197, 768
+M, d = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (256 * 197, 768)
+print(f"rows {M} x d {d}  lib {os.environ.get('SC_HIP_LIB', 'default')}")
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn(M, d, device=dev, generator=g)
