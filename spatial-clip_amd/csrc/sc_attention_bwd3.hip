@@ -357,7 +357,12 @@ __global__ __launch_bounds__(512) void attn_bwd3_kernel(const bf16* __restrict__
 #pragma unroll
         for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) vf[bt][ks] = vfn[bt][ks];
+            for (int ks = 0; ks < KS; ++ks) {
+                vf[bt][ks] = vfn[bt][ks];
+                // opaque to the compiler's wait pass: it does not see the counted wait above and would put a full `vmcnt(0)` in
+                // front of the next head's first MFMA -- i.e. wait for the eight dK / dV stores as well
+                asm volatile("" : "+v"(vf[bt][ks]));
+            }
         wg_barrier();                                      // A(i + 1)
     }
 }
@@ -390,7 +395,9 @@ int sc_attn_bwd_ring(const void* qkv, const void* out, const void* dout, const f
         ncu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }
     const int nheads = B * H;
-    const int grid = nheads < ncu ? nheads : ncu;
+    int grid = nheads < ncu ? nheads : ncu;
+    if (const char* e = getenv("SC_ATTN_GRID")) { const int gcap = atoi(e); if (gcap > 0 && gcap < grid) grid = gcap; }   // measurement: fewer workgroups
+
     const float scale = 1.0f / sqrtf((float)dh);
     const bf16 *q = (const bf16*)qkv, *o = (const bf16*)out, *g = (const bf16*)dout;
     bf16* dq = (bf16*)dqkv;

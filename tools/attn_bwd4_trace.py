@@ -36,9 +36,9 @@ for i in (1, 2):
     t0 = min(t[(i * 8 + w) * 32 + 0] for w in range(8))
     print(f"head {i} (us from the first wave's start; 100 MHz stamps)")
     for w in range(8):
-        r = [(t[(i * 8 + w) * 32 + s] - t0) / 100.0 for s in range(18)]
+        r = [(t[(i * 8 + w) * 32 + s] - t0) / 100.0 for s in range(20)]
         steps = " ".join(f"{r[1 + j]:5.1f}" for j in range(nbq))
-        print(f"  wave {w}: start {r[0]:5.1f} | steps end {steps} | reduce {r[12]:5.1f}-{r[13]:5.1f} | sweep + tail work done {r[14]:5.1f} "
+        print(f"  wave {w}: start {r[0]:5.1f} | steps end {steps} | reduces {r[12]:5.1f}-{r[13]:5.1f} {r[18]:5.1f}-{r[19]:5.1f} | sweep + tail work done {r[14]:5.1f} "
               f"next head's loads consumed {r[15]:5.1f} dK/dV stores issued {r[16]:5.1f} barrier {r[17]:5.1f}")
     t1 = min(t[((i + 1) * 8 + w) * 32 + 0] for w in range(8))
     print(f"  next head starts at {(t1 - t0) / 100.0:5.1f}")

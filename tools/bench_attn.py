@@ -38,5 +38,5 @@ for rep in range(int(os.environ.get("REPS", 2))):
     for name, b3, b2, b1 in (("bwd ring (r4)", "1", "0", "0"), ("bwd single-pass", "0", "0", "1"), ("bwd persistent", "0", "1", "0"),
                              ("bwd per-head", "0", "0", "0")):
         os.environ["SC_ATTN_BWD3"], os.environ["SC_ATTN_BWD2"], os.environ["SC_ATTN_BWD1"] = b3, b2, b1
-        timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, dh, False, dqkv=dqkv, delta=delta), name, 2 * qb + 3 * ob + qb)
+        timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, dh, False, dqkv=dqkv, delta=delta), name, 2 * qb + 2 * ob)       # qkv read, dqkv written, out and dout read
 os.environ.pop("SC_ATTN_BWD3"); os.environ.pop("SC_ATTN_BWD2"); os.environ.pop("SC_ATTN_BWD1")

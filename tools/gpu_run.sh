@@ -9,6 +9,7 @@
 #   prof[:single|side]                           rocprofv3 --kernel-trace --stats of the bench command (SC_OVERLAP=0 / default)
 #   pmc                                          the FETCH_SIZE / WRITE_SIZE / MFMA PMC passes + summaries
 #   py:<script and args>                         python <script ...> (tools/*.py micro-benchmarks)
+#   pmcpy:<script and args>                      the three PMC passes over python3 <script ...>
 #   env:VAR=VALUE / unset:VAR                    environment of the steps that follow (A/B switches)
 set -e -o pipefail
 TAG=$1; shift
@@ -47,6 +48,14 @@ for STEP in "$@"; do
       unset SC_OVERLAP
       python tools/pmc_summary.py $(find $OUT/pmc_f -name "f_counter_collection.csv") $(find $OUT/pmc_w -name "w_counter_collection.csv") $OUT/pmc_traffic_summary.json > $OUT/pmc_traffic.txt 2>&1; head -14 $OUT/pmc_traffic.txt
       python tools/pmc_generic.py $OUT/pmc_mfma_summary.json "$OUT/pmc_m/**/m_counter_collection.csv" > $OUT/pmc_mfma.txt 2>&1; head -14 $OUT/pmc_mfma.txt
+      find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
+    pmcpy)  # pmcpy:<script and args>: FETCH_SIZE / WRITE_SIZE / MFMA passes over a tools/*.py micro-benchmark (N=3 REPS=1 keep it short)
+      T="$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40)"
+      (cd /tmp && N=3 REPS=1 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmcpy_f_$T -o f -- python3 $R/$ARG > $R/$OUT/pmcpy_f_$T.log 2>&1)
+      (cd /tmp && N=3 REPS=1 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmcpy_w_$T -o w -- python3 $R/$ARG > $R/$OUT/pmcpy_w_$T.log 2>&1)
+      (cd /tmp && N=3 REPS=1 timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$OUT/pmcpy_m_$T -o m -- python3 $R/$ARG > $R/$OUT/pmcpy_m_$T.log 2>&1)
+      python tools/pmc_summary.py $(find $OUT/pmcpy_f_$T -name "f_counter_collection.csv") $(find $OUT/pmcpy_w_$T -name "w_counter_collection.csv") $OUT/pmcpy_traffic_$T.json > $OUT/pmcpy_traffic_$T.txt 2>&1; head -14 $OUT/pmcpy_traffic_$T.txt
+      python tools/pmc_generic.py $OUT/pmcpy_mfma_$T.json "$OUT/pmcpy_m_$T/**/m_counter_collection.csv" > $OUT/pmcpy_mfma_$T.txt 2>&1; head -14 $OUT/pmcpy_mfma_$T.txt
       find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
     env)    export "$ARG"; echo "exported $ARG" ;;
     unset)  unset "$ARG"; echo "unset $ARG" ;;
