@@ -357,12 +357,7 @@ __global__ __launch_bounds__(512) void attn_bwd3_kernel(const bf16* __restrict__
 #pragma unroll
         for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                vf[bt][ks] = vfn[bt][ks];
-                // opaque to the compiler's wait pass: it does not see the counted wait above and would put a full `vmcnt(0)` in
-                // front of the next head's first MFMA -- i.e. wait for the eight dK / dV stores as well
-                asm volatile("" : "+v"(vf[bt][ks]));
-            }
+            for (int ks = 0; ks < KS; ++ks) vf[bt][ks] = vfn[bt][ks];
         wg_barrier();                                      // A(i + 1)
     }
 }
