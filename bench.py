@@ -47,6 +47,8 @@ def skipped_flops_per_pair(cfg) -> float:
     v = cfg.vision
     L, d, mlp = v.tokens, v.width, int(v.width * v.mlp_ratio)
     fwd = (L - 1) * (2.0 * d * d + 2 * (2.0 * d * mlp)) + 2 * (2.0 * (L - 1) * L * d)
+    if os.environ.get("SC_CLS_Q", "1") != "0":
+        fwd += (L - 1) * 2.0 * d * d        # ... and, of its qkv projection, q for that one row (bf16 path)
     return 3.0 * fwd
 
 

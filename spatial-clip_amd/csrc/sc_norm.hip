@@ -3,6 +3,7 @@
 // One 64-lane wave owns one row; every access is a 16-byte (fp32x4) or 8-byte (bf16x4) vector.
 #include "sc_common.h"
 #include <stdlib.h>
+#include <mutex>
 #include "sc_kernels.h"
 #include "sc_gemm_common.h"   // sc_gelu_fast: the GELU of the GEMM epilogues
 
@@ -695,6 +696,8 @@ static int ln_resident_blocks(const void* fn, size_t lds, int nblk) {
     struct Slot { const void* fn; size_t lds; int blocks; };
     static Slot slots[64];
     static int nslots = 0;
+    static std::mutex mu;                       // (backward runs on the autograd engine's thread; tools call from the main one)
+    std::lock_guard<std::mutex> lock(mu);
     for (int i = 0; i < nslots; ++i)
         if (slots[i].fn == fn && slots[i].lds == lds) return nblk < slots[i].blocks ? nblk : slots[i].blocks;
     int per_cu = 0, dev = 0;

@@ -190,6 +190,20 @@ class TransformerStack:
             return ops.gemm(ops.NT, epi, x, cp.wf, out, M=M, N=N, K=K, **kw)
         return ops.gemm_fp8(epi, q8[0], q8[1], cp.w8, cp.w8s, out, M=M, N=N, K=K, **kw)
 
+    def _zero_bias(self, n: int) -> torch.Tensor:
+        z = self.bufs.get("zero.bias", (n,), F32)
+        if not getattr(self, "_zero_bias_set", False):
+            z.zero_()
+            self._zero_bias_set = True
+        return z
+
+    def _q_dead_ok(self, qa, i: int) -> bool:
+        """May the last block skip the q projection of the rows whose attention output nobody reads?  bf16 operands only (the
+        e4m3 GEMMs take whole-matrix scales), unpadded K; ``SC_CLS_Q=0`` restores the full projection."""
+        cp = self.s.copies[self._n(i, "attn.in_proj_weight")]
+        return (qa is None or cp.w8 is None) and cp.wf.shape[1] == self.d and self.d % 64 == 0 and \
+            os.environ.get("SC_CLS_Q", "1") != "0"
+
     def _q8(self, tag: str, M: int, K: int):
         """(e4m3 bytes [M, K], scale_inv [M]) scratch for a fused quantiser output, or None off the fp8 path."""
         if not self.fp8:
@@ -234,11 +248,22 @@ class TransformerStack:
             ops.layernorm_fwd(x, s.p(self._n(i, "ln_1.weight")), s.p(self._n(i, "ln_1.bias")), a1, m1, r1, M, d,
                               q8=qa and qa[0], q8_scale_inv=qa and qa[1])
             qkv = bf.get(f"qkv.{i}", (M, 3 * d), BF16)
-            self._linear_fwd(ops.EPI_BF16_BIAS, a1, self._n(i, "attn.in_proj_weight"), qkv,
-                             M=M, N=3 * d, K=d, bias=s.p(self._n(i, "attn.in_proj_bias")), q8=qa)
+            last_cls = self.cls_only_last and i == self.layers - 1
+            self._q_cls_only = last_cls and self._q_dead_ok(qa, i)
+            if self._q_cls_only:
+                # last block, only the class token is consumed: K and V of every token, but Q of the class tokens alone -- the
+                # other rows' q (a third of this GEMM, of its data gradient and of its weight gradient) is never read
+                wq = s.copies[self._n(i, "attn.in_proj_weight")].wf
+                bq = s.p(self._n(i, "attn.in_proj_bias"))
+                ops.gemm(ops.NT, ops.EPI_BF16_BIAS, a1, wq[d:], qkv[:, d:], M=M, N=2 * d, K=d, bias=bq[d:])
+                ops.gemm(ops.NT, ops.EPI_BF16_BIAS, a1.view(B, L * d)[:, :d], wq[:d], qkv.view(B, L * 3 * d)[:, :d],
+                         M=B, N=d, K=d, bias=bq[:d])
+            else:
+                self._linear_fwd(ops.EPI_BF16_BIAS, a1, self._n(i, "attn.in_proj_weight"), qkv,
+                                 M=M, N=3 * d, K=d, bias=s.p(self._n(i, "attn.in_proj_bias")), q8=qa)
             o = bf.get(f"o.{i}", (M, d), BF16)
             lse = bf.get(f"lse.{i}", (B, H, L), F32)
-            if self.cls_only_last and i == self.layers - 1:
+            if last_cls:
                 return self._forward_last_cls(i, x, qkv, o, lse)
             ops.attn_fwd(qkv, B, L, H, dh, self.causal, out=o, lse=lse)
             xmid = bf.get(f"xmid.{i}", (M, d), XD)
@@ -336,13 +361,27 @@ class TransformerStack:
         ops.attn_bwd(qkv, o, dO, lse, B, L, H, dh, self.causal, dqkv=dqkv, delta=bf.get("delta", (B, H, L), F32),
                      q_rows=1)
 
+        q_cls = getattr(self, "_q_cls_only", False)      # the forward projected q for the class tokens only
+        dq_c, a1_c = dqkv.view(B, L * 3 * d)[:, :d], a1.view(B, L * d)[:, :d]
+
         def w_attn():
             ops.gemm(ops.TN, ops.EPI_F32, g1_c, o_c, g("attn.out_proj.weight"), M=d, N=d, K=B)
-            ops.gemm_wgrad_bias(dqkv, a1, g("attn.in_proj_weight"), g("attn.in_proj_bias"), M=3 * d, N=d, K=M,
-                                splitk=_splitk_for(3 * d, d, M))
+            if q_cls:       # dq is zero off the class-token rows: W_q's gradient from those B rows, W_k / W_v's from all
+                gw, gb = g("attn.in_proj_weight"), g("attn.in_proj_bias")
+                ops.gemm_wgrad_bias(dqkv[:, d:], a1, gw[d:], gb[d:], M=2 * d, N=d, K=M, splitk=_splitk_for(2 * d, d, M))
+                ops.gemm_wgrad_bias(dq_c, a1_c, gw[:d], gb[:d], M=d, N=d, K=B)
+            else:
+                ops.gemm_wgrad_bias(dqkv, a1, g("attn.in_proj_weight"), g("attn.in_proj_bias"), M=3 * d, N=d, K=M,
+                                    splitk=_splitk_for(3 * d, d, M))
         on_side(w_attn, (dqkv,))
         dA = bf.get("dA", (M, d), BF16)
-        ops.gemm(ops.NT, ops.EPI_BF16, dqkv, cp("attn.in_proj_weight").wb, dA, M=M, N=d, K=3 * d)
+        wb = cp("attn.in_proj_weight").wb
+        if q_cls:           # data gradient: the k | v columns for every row, then the q columns added on the class-token rows
+            ops.gemm(ops.NT, ops.EPI_BF16, dqkv[:, d:], wb[:, d:], dA, M=M, N=d, K=2 * d)
+            dA_c = dA.view(B, L * d)[:, :d]
+            ops.gemm(ops.NT, ops.EPI_BF16_BIAS_RES, dq_c, wb[:, :d], dA_c, M=B, N=d, K=d, bias=self._zero_bias(d), res=dA_c)
+        else:
+            ops.gemm(ops.NT, ops.EPI_BF16, dqkv, wb, dA, M=M, N=d, K=3 * d)
         dres_bf = bf.get("dres_bf.0", (M, d), BF16)
         prev_bias = s.g(self._n(i - 1, "mlp.c_proj.bias")) if i > 0 else None
         qg = self._q8("g", M, d)

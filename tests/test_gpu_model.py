@@ -603,6 +603,51 @@ def test_grad_checkpointing_is_bit_identical_and_saves_buffers(monkeypatch, over
     assert "a1.3" in res[True][3]           # the CLS-only last block keeps its own LayerNorm output
 
 
+def test_last_block_projects_q_for_the_class_tokens_only(monkeypatch):
+    """The last ViT block's attention output is read for the class token alone (pool 'tok'), so q of the other rows is dead
+    work: by default the block projects K | V for every token and Q for the B class tokens, and its data / weight gradients
+    leave the zero dq rows out (round 5).  Against the full projection (SC_CLS_Q=0) on the same weights and batch: same
+    features to bf16 GEMM rounding (another kernel multiplies the class rows' q), every gradient tensor within 2 % relative L2
+    (measured 0.8 %: the class rows' data gradient is rounded to bf16 once more), and both within the suite's bound of the fp32 oracle."""
+    data, losses, mc, module, net, optim = _pkg()
+    cfg, ocfg = tiny_cfgs(128, 64, 4, 48, 16)
+    B = 16
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=11)
+    perturb(n)
+    params = {k: v.cpu() for k, v in n.state_dict().items()}
+    batch = data.synthetic_batch(B, 48, cfg.gene.n_genes, K=4, step=0)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    f = O.net_forward(batch["images"], batch["texts"], p, ocfg)
+    O.clip_loss(f["image_features"], f["text_features"], f["logit_scale"]).backward()
+    m = module.SpatialClipLitModule(n, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True), None, None)
+    db = {k: v.cuda() for k, v in batch.items()}
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SC_CLS_Q", mode)
+        n.store.grad.zero_()
+        last = n.vision.stack.layers - 1
+        n.vision.stack.bufs.get(f"qkv.{last}", (B * 10, 3 * 128), torch.bfloat16).fill_(float("nan"))   # (10 tokens: 3 x 3 patches + class)
+        # ... whatever the block does not write must not be read
+        out = m.model_step(db)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        assert n.vision.stack._q_cls_only == (mode == "1")
+        res[mode] = (float(out["loss"].detach()), out["image_features"].detach().float().cpu(),
+                     {k: n.store.g(k).detach().cpu().double().clone() for k in params})
+    assert abs(res["0"][0] - res["1"][0]) < 2e-4 and float((res["0"][1] - res["1"][1]).abs().max()) < 2e-3
+    worst_pair, worst_ref = 0.0, 0.0
+    for k in params:
+        g_ref = p[k].grad.double() if p[k].grad is not None else None
+        a, b = res["0"][2][k], res["1"][2][k]
+        assert bool(torch.isfinite(b).all()), k
+        if float(a.norm()) > 1e-6:
+            worst_pair = max(worst_pair, float((a - b).norm() / a.norm()))
+        if g_ref is not None and float(g_ref.norm()) > 1e-5:
+            worst_ref = max(worst_ref, float((b - g_ref).norm() / g_ref.norm()))
+    print(f"q for the class tokens only vs full projection: worst relative L2 {worst_pair:.5f}; vs oracle {worst_ref:.4f}")
+    assert worst_pair < 0.02 and worst_ref < 0.06
+
+
 def test_residual_gradient_fp32_buffer_and_bf16_stream_agree(monkeypatch):
     """SC_RES_GRAD=fp32 (the fp32 residual-gradient buffer of rounds 1-2) and the default bf16 stream on the same weights and
     batch: same loss bits (the forward is untouched), gradients within 2 % relative L2 per tensor of each other (the stream rounds
