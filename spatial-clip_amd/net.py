@@ -59,6 +59,7 @@ class _NetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_img, d_txt, d_s):
+        ctx.net.store.wait_all()      # an optimiser update running behind the forward reads the gradients this backward overwrites
         ctx.net._backward(d_img, d_txt, d_s)
         return None, None, None, None
 

@@ -9,6 +9,7 @@ bf16 compute-copy refresh.  ``get_cosine_schedule_with_warmup`` reproduces trans
 from __future__ import annotations
 
 import math
+import os
 from typing import Iterable, Optional
 
 import torch
@@ -36,6 +37,7 @@ class FusedAdamW:
         self.norm_clip = torch.zeros(2, dtype=torch.float32, device=dev)
         self.step_count = 0
         self.exchange = None        # comm.ShardedGradExchange when this rank owns 1/W of every gradient bucket
+        self._behind = None         # bucket plan of the replicated optimiser's overlapped form (_step_behind_forward)
 
     def attach_exchange(self, exchange) -> None:
         """Data-parallel runs: hand the optimiser the gradient exchange of the process group.  With a
@@ -80,6 +82,61 @@ class FusedAdamW:
             ex.gather_bucket(k)
         return self.norm_clip
 
+    # ---- replicated optimiser, update hidden behind the next forward (round 5)
+    def _behind_plan(self, bucket_floats: int = 16 * 1024 * 1024):
+        """Static buckets of the flat buffers in the order the forward consumes them (the second tower runs first and sits at
+        the END of the buffers), each with the derived weight copies that are complete once it is."""
+        if self._behind is None:
+            st = self.store
+            size = max(64, (int(bucket_floats) + 63) // 64 * 64)
+            edges = list(range(0, st.total, size)) + [st.total]
+            if len(edges) > 2 and edges[-1] - edges[-2] < size // 2:
+                edges.pop(-2)
+            buckets = [(edges[k], edges[k + 1]) for k in range(len(edges) - 1)]
+            first_second = min((sp.offset for sp in st.specs if not sp.name.startswith("visual.")), default=0)
+            k0 = next(k for k, (lo, hi) in enumerate(buckets) if lo <= first_second < hi)
+            order = list(range(k0, len(buckets))) + list(range(0, k0))
+            pos = {k: i for i, k in enumerate(order)}
+            copies = [[] for _ in buckets]
+            for c in st.copies.values():
+                sp = st.by_name[c.name]
+                touched = [k for k, (lo, hi) in enumerate(buckets) if lo < sp.offset + sp.numel and sp.offset < hi]
+                copies[max(touched, key=lambda k: pos[k])].append(c)
+            self._behind = (buckets, order, copies, [st._transpose_plan(cs) for cs in copies])
+        return self._behind
+
+    def _step_behind_forward(self, grad_scale: float, max_norm: Optional[float]) -> torch.Tensor:
+        """The replicated update (one process, or the all-reduce route) bucket by bucket on the communication stream, in the order
+        the next forward consumes the buckets: the forward waits per bucket at the first use of its parameters
+        (``ParamStore.wait_names``, the mechanism of the sharded optimiser), so all but the first bucket of the HBM-bound update
+        (30 bytes per parameter) runs under the matrix-bound start of the next step.  Same kernels on the same values: weights
+        bit-identical to the one-launch form (``SC_ADAMW_BEHIND=0``)."""
+        from . import streams
+        g = self.param_groups[0]
+        st = self.store
+        st.wait_all()               # a step without a forward in between: the previous update must be complete
+        clip = None
+        if max_norm is not None and max_norm > 0:
+            ops.grad_norm(st.grad, st.total, grad_scale, max_norm, self.norm_clip)
+            clip = self.norm_clip
+        buckets, order, copies, plans = self._behind_plan(int(os.environ.get("SC_ADAMW_BUCKET", 16 * 1024 * 1024)))
+        cur = torch.cuda.current_stream(st.device)
+        side = streams.comm_stream(st.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            for k in order:
+                lo, hi = buckets[k]
+                ops.adamw_step(st.master[lo:hi], st.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], hi - lo, g["lr"],
+                               g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count, grad_scale, clip,
+                               st.master_bf16[lo:hi])
+                st.refresh_range(lo, hi, copies[k], plans[k], fresh=(lo, hi))
+                done = torch.cuda.Event()
+                done.record(side)
+                st.pending.append((lo, hi, done))
+        return self.norm_clip
+
     def zero_grad(self, set_to_none: bool = False) -> None:
         """Gradients are overwritten by every backward; nothing to clear."""
 
@@ -89,6 +146,8 @@ class FusedAdamW:
         self.step_count += 1
         if self.exchange is not None:
             return self._step_sharded(grad_scale, max_norm)
+        if st.master.is_cuda and os.environ.get("SC_ADAMW_BEHIND", "1") != "0":
+            return self._step_behind_forward(grad_scale, max_norm)
         clip = None
         if max_norm is not None and max_norm > 0:
             ops.grad_norm(st.grad, st.total, grad_scale, max_norm, self.norm_clip)
@@ -101,6 +160,7 @@ class FusedAdamW:
     def state_dict(self):
         """Full flat-layout moments whatever the exchange (a checkpoint written by W ranks resumes on any W').  With the
         sharded exchange this is a COLLECTIVE: every rank must call it (the trainer does, before rank 0 writes the file)."""
+        self.store.wait_all()           # an update may still be running behind the forward (communication stream)
         if self.exchange is not None:
             m, v = self.exchange.gather_moments(self.exp_avg), self.exchange.gather_moments(self.exp_avg_sq)
         else:
@@ -109,6 +169,7 @@ class FusedAdamW:
                 "param_groups": [{k: v_ for k, v_ in self.param_groups[0].items() if k != "params"}]}
 
     def load_state_dict(self, sd) -> None:
+        self.store.wait_all()
         self.step_count = int(sd["step"])
         n = self.store.total
         m, v = sd["exp_avg"], sd["exp_avg_sq"]

@@ -603,6 +603,54 @@ def test_grad_checkpointing_is_bit_identical_and_saves_buffers(monkeypatch, over
     assert "a1.3" in res[True][3]           # the CLS-only last block keeps its own LayerNorm output
 
 
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_adamw_behind_the_next_forward_is_bit_identical(monkeypatch, overlap):
+    """The replicated optimiser's update runs bucket by bucket on the communication stream and the next forward waits per
+    bucket (round 5): losses, weights and Adam moments after four steps equal the one-launch form's bit for bit -- several
+    buckets (SC_ADAMW_BUCKET), both backward schedules, a state_dict() and an evaluation forward taken right behind a step."""
+    import functools
+    data, losses, mc, module, net, optim = _pkg()
+    monkeypatch.setenv("SC_OVERLAP", overlap)
+    monkeypatch.setenv("SC_ADAMW_BUCKET", "40000")
+    cfg, _ = genetr_cfgs(width=128, head_width=64, layers=3, image=48, patch=16, glayers=2, gwidth=64, ghead=32)
+    B = 16
+    res = {}
+    for behind in ("0", "1"):
+        monkeypatch.setenv("SC_ADAMW_BEHIND", behind)
+        n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=5)
+        perturb(n)
+        m = module.SpatialClipLitModule(
+            n, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True),
+            functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+            functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
+
+        class T:
+            max_steps, max_epochs, estimated_stepping_batches = 10, None, 10
+        m.trainer = T()
+        oc = m.configure_optimizers()
+        opt, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+        ls = []
+        for s in range(4):
+            b = data.synthetic_batch(B, 48, cfg.gene.n_genes, K=4, step=s)
+            loss = m.training_step({k: v.cuda() for k, v in b.items()}, s)
+            loss.backward()
+            opt.step(grad_scale=1.0, max_norm=1.0)
+            sched.step()
+            ls.append(float(loss.detach()))
+        if behind == "1":
+            assert len(opt._behind[0]) >= 3 and n.store.pending          # several buckets, and the update is still registered
+        sd = n.state_dict()                                                  # waits for the update
+        osd = opt.state_dict()
+        with torch.no_grad():
+            b = data.synthetic_batch(B, 48, cfg.gene.n_genes, K=4, step=9)
+            feats = n.model.encode_image(b["images"].cuda()).float().cpu()
+        torch.cuda.synchronize()
+        res[behind] = (ls, {k: v.cpu() for k, v in sd.items()}, osd["exp_avg"].cpu(), osd["exp_avg_sq"].cpu(), feats)
+    assert res["0"][0] == res["1"][0]
+    assert all(torch.equal(res["0"][1][k], res["1"][1][k]) for k in res["0"][1])
+    assert torch.equal(res["0"][2], res["1"][2]) and torch.equal(res["0"][3], res["1"][3]) and torch.equal(res["0"][4], res["1"][4])
+
+
 def test_last_block_projects_q_for_the_class_tokens_only(monkeypatch):
     """The last ViT block's attention output is read for the class token alone (pool 'tok'), so q of the other rows is dead
     work: by default the block projects K | V for every token and Q for the B class tokens, and its data / weight gradients

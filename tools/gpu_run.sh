@@ -31,10 +31,10 @@ for STEP in "$@"; do
     bench)  timeout -k 10 900 python bench.py --steps 20 --warmup 5 $ARG > "$OUT/bench_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40).json" 2> "$OUT/bench_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40).err" ; tail -c 600 "$OUT"/bench_*.json | tail -5 ;;
     benchq) timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loss-delta --no-kernel-events $ARG 2> "$OUT/benchq.err" | tee -a "$OUT/benchq.jsonl" | cut -c1-400 ;;
     prof)
-      MODE=${ARG:-single}
+      MODE=${ARG%% *}; MODE=${MODE:-single}; EXTRA=""; [[ "$ARG" == *" "* ]] && EXTRA=${ARG#* }      # prof:single+--model+X ...: extra bench.py arguments
       D=$PWD/$OUT/prof_$MODE; rm -rf $D
       if [ "$MODE" = single ]; then export SC_OVERLAP=0; else unset SC_OVERLAP; fi
-      (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o s -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-events --no-loss-delta > $R/$OUT/prof_$MODE.log 2>&1)
+      (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o s -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-events --no-loss-delta $EXTRA > $R/$OUT/prof_$MODE.log 2>&1)
       unset SC_OVERLAP
       find $D -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_$MODE.csv" \;
       find $D -name '*kernel_trace.csv' -size +20M -delete
