@@ -33,19 +33,20 @@ for STEP in "$@"; do
     prof)
       MODE=${ARG%% *}; MODE=${MODE:-single}; EXTRA=""; [[ "$ARG" == *" "* ]] && EXTRA=${ARG#* }      # prof:single+--model+X ...: extra bench.py arguments
       D=$PWD/$OUT/prof_$MODE; rm -rf $D
-      if [ "$MODE" = single ]; then export SC_OVERLAP=0; else unset SC_OVERLAP; fi
+      # single: every kernel alone on the chip -- weight gradients on the chain stream AND the optimiser as one launch in front of the forward
+      if [ "$MODE" = single ]; then export SC_OVERLAP=0 SC_ADAMW_BEHIND=0; else unset SC_OVERLAP SC_ADAMW_BEHIND; fi
       (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o s -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-events --no-loss-delta $EXTRA > $R/$OUT/prof_$MODE.log 2>&1)
-      unset SC_OVERLAP
+      unset SC_OVERLAP SC_ADAMW_BEHIND
       find $D -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_$MODE.csv" \;
       find $D -name '*kernel_trace.csv' -size +20M -delete
       head -30 "$OUT/kernel_stats_$MODE.csv" | cut -c1-200 ;;
     pmc)
-      export SC_OVERLAP=0
+      export SC_OVERLAP=0 SC_ADAMW_BEHIND=0
       B="python3 $R/bench.py --no-cpu-baseline --no-kernel-events --no-loss-delta"
       (cd /tmp && timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_f -o f -- $B --steps 3 --warmup 1 > $R/$OUT/pmc_f.log 2>&1)
       (cd /tmp && timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_w -o w -- $B --steps 3 --warmup 1 > $R/$OUT/pmc_w.log 2>&1)
       (cd /tmp && timeout -k 10 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$OUT/pmc_m -o m -- $B --steps 2 --warmup 1 > $R/$OUT/pmc_m.log 2>&1)
-      unset SC_OVERLAP
+      unset SC_OVERLAP SC_ADAMW_BEHIND
       python tools/pmc_summary.py $(find $OUT/pmc_f -name "f_counter_collection.csv") $(find $OUT/pmc_w -name "w_counter_collection.csv") $OUT/pmc_traffic_summary.json > $OUT/pmc_traffic.txt 2>&1; head -14 $OUT/pmc_traffic.txt
       python tools/pmc_generic.py $OUT/pmc_mfma_summary.json "$OUT/pmc_m/**/m_counter_collection.csv" > $OUT/pmc_mfma.txt 2>&1; head -14 $OUT/pmc_mfma.txt
       find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
