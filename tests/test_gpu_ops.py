@@ -184,7 +184,7 @@ def test_attention_bwd_ring8_for_225_to_257_tokens(B, L, H, monkeypatch):
     torch.testing.assert_close(dq1.float().cpu()[last], x.grad[last], atol=4e-2, rtol=4e-2)
 
 
-@pytest.mark.parametrize("rows,d", [(50, 768), (197 * 2, 192), (33, 64), (7, 1024)])
+@pytest.mark.parametrize("rows,d", [(50, 768), (197 * 2, 192), (33, 64), (7, 1024), (4500, 1024)])     # (4500 rows: more blocks than are resident at d = 1024)
 def test_layernorm_fwd_bwd(rows, d):
     ops = _ops()
     g = torch.Generator().manual_seed(rows)
@@ -230,7 +230,7 @@ def test_layernorm_fwd_bwd(rows, d):
         assert torch.equal(dres2, dres) and torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(cs2, cs)
 
 
-@pytest.mark.parametrize("rows,d", [(50, 768), (197 * 2, 192), (33, 1024)])
+@pytest.mark.parametrize("rows,d", [(50, 768), (197 * 2, 192), (33, 1024), (4500, 1024)])
 def test_layernorm_bf16_rows_and_bf16_gradient_stream(rows, d):
     """sc_layernorm_fwd_x16 / _bwd_x16 / _bwd_g16: rows of the residual stream read as bf16 give the bits of the fp32 kernels
     fed with float(x) (the widening is exact); the bf16 gradient stream gout = bf16(float(gin) + LNbwd(dy)) equals the fp32
