@@ -87,6 +87,10 @@ int sc_gemm_wgrad_group(const sc_wgrad_desc* descs, int n, int K, int splitk, fl
  * BF16_DGELU / F32).  NT only: C[M,N] = A8[M,K] . B8[N,K]^T, K % 128 == 0, lda / ldb in bytes (= elements), multiples of 16. */
 int sc_quantize_rows_fp8(const void* src, int src_is_f32, long long ld_src, int rows, int cols, void* dst_fp8,
                          long long ld_dst, float* scale_inv, float fixed_scale, void* stream);
+/* The same for n matrices in ONE launch (the e4m3 copies of all Linear weights after an optimiser step; device tables):
+ * desc[8 i ..] = {src pointer, src_is_f32, ld_src, rows, cols, dst pointer, ld_dst, scale_inv pointer} as int64,
+ * block_prefix[i] = first 4-row block of matrix i, block_prefix[n] = total_blocks.  Same shape / alignment rules per matrix. */
+int sc_quantize_rows_fp8_batched(const long long* desc, const int* block_prefix, int n, int total_blocks, void* stream);
 int sc_gemm_fp8(int epi, const void* A8, int lda, const float* a_scale_inv, const void* B8, int ldb,
                 const float* b_scale_inv, int M, int N, int K, void* C, int ldc, void* C2, int ldc2, const float* bias,
                 const void* res, int ldres, const void* aux, int ldaux, void* stream);

@@ -624,6 +624,12 @@ def augment_tiles(src_u8: torch.Tensor, params: torch.Tensor, out_size: int, mea
 
 
 # ------------------------------------------------------------------------------------------ fp8 forward path
+def quantize_rows_fp8_batched(desc: torch.Tensor, block_prefix: torch.Tensor, n: int, total_blocks: int) -> None:
+    """Row-wise e4m3 copies of ``n`` matrices in one launch (params.ParamStore._q8_plan builds the device tables)."""
+    check(_lib.lib().sc_quantize_rows_fp8_batched(desc.data_ptr(), block_prefix.data_ptr(), n, total_blocks, _stream()),
+          "sc_quantize_rows_fp8_batched")
+
+
 def quantize_rows_fp8(src: torch.Tensor, dst: Optional[torch.Tensor] = None, scale_inv: Optional[torch.Tensor] = None,
                       fixed_scale: float = 0.0):
     """Row-wise e4m3 quantisation with a power-of-two scale per row: -> (fp8 bytes as uint8 [rows, cols], 1/scale [rows])."""

@@ -11,6 +11,8 @@ import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -333,17 +335,46 @@ class ParamStore:
         return (torch.tensor(desc, dtype=torch.int64, device=self.device),
                 torch.tensor(prefix, dtype=torch.int32, device=self.device), len(desc), tiles)
 
+    def _q8_plan(self, copies):
+        """Device tables of ops.quantize_rows_fp8_batched for the e4m3 copies of ``copies`` (cached per set of weights: every
+        pointer in it belongs to a persistent buffer)."""
+        key = tuple(c.name for c in copies)
+        cache = self.__dict__.setdefault("_q8_plans", {})
+        if key not in cache:
+            desc, prefix, blocks = [], [0], 0
+            for c in copies:
+                items = []
+                if c.w8 is not None:
+                    src = self.p(c.name).view(c.n_out, c.k_in)
+                    items.append((src, 1, c.w8, c.w8s))
+                if c.wb8 is not None:
+                    items.append((c.wb, 0, c.wb8, c.wb8s))
+                for src, f32, dst, sinv in items:
+                    rows, cols = src.shape
+                    if cols % 8 or dst.stride(0) % 8 or src.stride(0) % (4 if f32 else 8) or src.data_ptr() % 16 or dst.data_ptr() % 8:
+                        raise ValueError(f"e4m3 copy of {c.name}: shape / alignment outside sc_quantize_rows_fp8's rules")
+                    desc.append([src.data_ptr(), f32, src.stride(0), rows, cols, dst.data_ptr(), dst.stride(0), sinv.data_ptr()])
+                    blocks += (rows + 3) // 4
+                    prefix.append(blocks)
+            cache[key] = None if not desc else (torch.tensor(desc, dtype=torch.int64, device=self.device),
+                                                torch.tensor(prefix, dtype=torch.int32, device=self.device), len(desc), blocks)
+        return cache[key]
+
     def _refresh_copies(self, copies, plan) -> None:
         """Everything derived from the (fresh) bf16 mirror / fp32 masters for the Linear weights in ``copies``."""
         if plan is not None:
             desc, prefix, n, tiles = plan
             ops.cast_transpose_batched(self.master, desc, prefix, n, tiles, mirror_bf16=self.master_bf16)
         if self.fp8:                                      # per-output-channel e4m3 copies straight from the fp32 masters
-            for c in copies:
-                if c.w8 is not None:
-                    ops.quantize_rows_fp8(self.p(c.name).view(c.n_out, c.k_in), c.w8, c.w8s)
-                if c.wb8 is not None:                     # rows of the transposed bf16 copy = input channels
-                    ops.quantize_rows_fp8(c.wb, c.wb8, c.wb8s)
+            q8 = self._q8_plan(copies)                    # ... and of the transposed bf16 copies (rows = input channels): ONE launch
+            if q8 is not None and os.environ.get("SC_Q8_BATCH", "1") != "0":
+                ops.quantize_rows_fp8_batched(*q8)
+            else:                                         # A/B: one launch per matrix (rounds 2-4; same bits)
+                for c in copies:
+                    if c.w8 is not None:
+                        ops.quantize_rows_fp8(self.p(c.name).view(c.n_out, c.k_in), c.w8, c.w8s)
+                    if c.wb8 is not None:
+                        ops.quantize_rows_fp8(c.wb, c.wb8, c.wb8s)
         for c in copies:
             if not c.stored_kn and not c.wf_is_view:      # K-padded forward operand (gene.fc1, conv1 at patch 14)
                 ops.cast_pad_bf16(self.p(c.name).view(c.n_out, c.k_in), c.wf, c.n_out, c.k_in, c.k_pad,

@@ -41,6 +41,37 @@ def test_quantiser_rows_power_of_two_and_round_trip():
     assert torch.equal(s2, torch.full((37,), 0.25, device="cuda"))
 
 
+def test_batched_row_quantiser_gives_the_bits_of_the_single_launches():
+    """sc_quantize_rows_fp8_batched (round 5: the e4m3 copies of every Linear weight in ONE launch after an optimiser step):
+    fp32 and bf16 sources, row counts that are no multiple of a block's four rows, strided sources -- byte for byte what one
+    sc_quantize_rows_fp8 call per matrix writes, scales included, and nothing outside the destinations."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    mats = []
+    for rows, cols, f32, pad in ((37, 256, True, 0), (1024, 768, False, 0), (5, 64, True, 8), (130, 1024, False, 16), (1, 8, True, 0)):
+        full = (torch.randn(rows, cols + pad, generator=g) * torch.logspace(-2, 1, rows).view(-1, 1)).cuda()
+        if not f32:
+            full = full.bfloat16()
+        mats.append(full[:, :cols])
+    desc, prefix, blocks, dsts, sinvs = [], [0], 0, [], []
+    for src in mats:
+        rows, cols = src.shape
+        dst = torch.full((rows + 1, cols), 0xAB, dtype=torch.uint8, device="cuda")      # one guard row behind every copy
+        sinv = torch.full((rows + 1,), -7.0, device="cuda")
+        dsts.append(dst); sinvs.append(sinv)
+        desc.append([src.data_ptr(), int(src.dtype == torch.float32), src.stride(0), rows, cols, dst.data_ptr(), dst.stride(0),
+                     sinv.data_ptr()])
+        blocks += (rows + 3) // 4
+        prefix.append(blocks)
+    ops.quantize_rows_fp8_batched(torch.tensor(desc, dtype=torch.int64, device="cuda"),
+                                  torch.tensor(prefix, dtype=torch.int32, device="cuda"), len(desc), blocks)
+    for src, dst, sinv in zip(mats, dsts, sinvs):
+        q, s1 = ops.quantize_rows_fp8(src)
+        rows = src.shape[0]
+        assert torch.equal(dst[:rows], q) and torch.equal(sinv[:rows], s1)
+        assert bool((dst[rows] == 0xAB).all()) and float(sinv[rows]) == -7.0
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 384), (1024, 768, 768), (197 * 8, 3072, 768)])
 def test_gemm_fp8_is_exact_on_representable_data(M, N, K):
     """Small integers x power-of-two row scales: every product and partial sum is exact in fp32, so the kernel must
