@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         if constexpr (LEAN) {
             // Wide rows (d = 1024: NV = 4) with bf16 rows and a bf16 gradient stream: the row's three inputs stay in their
             // packed bf16 form (24 registers instead of the 40 of g / x_hat in fp32) and dy * gamma, x_hat are formed twice,
-            // gamma re-read from L1 -- 140 -> under 128 VGPRs, the fourth wave per SIMD (same arithmetic, same order).
-            static_assert(GIN && XB && !Q8, "lean row body: bf16 rows, bf16 gradient stream, no e4m3 copy");
+            // gamma re-read from L1 -- 140 -> under 128 VGPRs, the fourth wave per SIMD (same arithmetic, same order).  With
+            // the e4m3 copies (Q8) the new gradient is formed a THIRD time once the row's scale is known, instead of being kept.
+            static_assert(GIN && XB, "lean row body: bf16 rows, bf16 gradient stream");
             bf16x4 dyp[NV], xp[NV], gp[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                     xp[i] = *reinterpret_cast<const bf16x4*>(xrb + e * 4);
                 }
             }
-            float s1 = 0.f, s2 = 0.f;
+            float s1 = 0.f, s2 = 0.f, amax_l = 0.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int e = i * 64 + lane;
@@ -223,12 +224,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                     for (int c = 0; c < 4; ++c) {
                         const float xhv = __fmul_rn((float)xp[i][c] - mu, rs);
                         const float gv = __fmul_rn((float)dyp[i][c], gmv[c]);
-                        o[c] = (float)gp[i][c] + rs * (gv - s1 - xhv * s2);
+                        o[c] = __fmaf_rn(rs, __fmaf_rn(-xhv, s2, __fsub_rn(gv, s1)), (float)gp[i][c]);     // (pinned: formed again below)
                         ac[i][c] += o[c];
+                        if (Q8) amax_l = fmaxf(amax_l, fabsf(o[c]));
                     }
                     if (write_f32) st4(dr + e * 4, o);
                     if (db) stbf4(db + e * 4, o);
                 }
+            }
+            if constexpr (Q8) {
+                const float sc = ln_row_scale(amax_l);
+                if (lane == 0) scale_inv[row] = 1.0f / sc;
+                unsigned char* d8r = d8 + (long long)row * ldd8;
+                const bool tt = t8.t8 != nullptr;
+                const float ts = tt ? *t8.t_scale : 1.0f;
+                unsigned char* tr = tt ? t8.t8 + (long long)row * t8.ldt8 : nullptr;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {   // opaque again: or the second pass's values stay alive for this one
+                    union { bf16x4 v; u32x2 u; } a, b, cc;
+                    a.v = dyp[i]; b.v = xp[i]; cc.v = gp[i];
+                    asm volatile("" : "+v"(a.u), "+v"(b.u), "+v"(cc.u));
+                    dyp[i] = a.v; xp[i] = b.v; gp[i] = cc.v;
+                }
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int e = i * 64 + lane;
+                    if (e < nv) {
+                        const f32x4 gmv = ld4(gamma + e * 4);
+                        f32x4 o;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float xhv = __fmul_rn((float)xp[i][c] - mu, rs);
+                            const float gv = __fmul_rn((float)dyp[i][c], gmv[c]);
+                            o[c] = __fmaf_rn(rs, __fmaf_rn(-xhv, s2, __fsub_rn(gv, s1)), (float)gp[i][c]);
+                        }
+                        *reinterpret_cast<unsigned*>(d8r + e * 4) = ln_pack4_fp8(o, sc);
+                        if (tt) *reinterpret_cast<unsigned*>(tr + e * 4) = ln_pack4_fp8(o, ts);
+                    }
+                }
+                if (tt) ln_t8_amax(sc_wave_max(amax_l), t8.t_amax, row);
             }
             continue;
         }
@@ -748,23 +782,25 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
     // lean row body (bf16 rows + bf16 gradient stream, no e4m3 copies): d = 1024 by default; SC_LN_BWD_LEAN=0 off, =3 also d = 768
     const char* lean_env = getenv("SC_LN_BWD_LEAN");      // read per call: the tests run both bodies in one process
     const int lean_mode = lean_env ? atoi(lean_env) : 4;
-    const bool lean_ok = xb && d8 == nullptr && gin != nullptr && accumulate > 0 && lean_mode != 0;
-#define SC_LN_BWD_LEAN(NV)                                                                                              \
+    const bool lean_ok = xb && gin != nullptr && accumulate > 0 && lean_mode != 0;
+#define SC_LN_BWD_LEAN_Q(NV, Q)                                                                                         \
     do {                                                                                                                \
         if (lds > 48 * 1024)                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, false, true, true, true>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, Q, true, true, true>),           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        const int grid = ln_resident_blocks(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, false, true, true, true>), \
+        const int grid = ln_resident_blocks(reinterpret_cast<const void*>(&ln_bwd_kernel<NV, Q, true, true, true>),     \
                                             lds, nblk);                                                                 \
-        ln_bwd_kernel<NV, false, true, true, true><<<grid, 256, lds, st>>>(                                             \
+        ln_bwd_kernel<NV, Q, true, true, true><<<grid, 256, lds, st>>>(                                                 \
             (const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, lddres, (bf16*)dres_bf16, lddbf, ws, rows, d,       \
-            accumulate, nullptr, 0, nullptr, (const bf16*)gin, ldgin, write_f32, t8, nblk);                             \
+            accumulate, (unsigned char*)d8, ldd8, scale_inv, (const bf16*)gin, ldgin, write_f32, t8, nblk);             \
     } while (0)
+#define SC_LN_BWD_LEAN(NV) do { if (d8) SC_LN_BWD_LEAN_Q(NV, true); else SC_LN_BWD_LEAN_Q(NV, false); } while (0)
     if (lean_ok && nvv == 4) SC_LN_BWD_LEAN(4);
     else if (lean_ok && nvv == 3 && lean_mode == 3) SC_LN_BWD_LEAN(3);
     else if (nvv <= 1) SC_LN_BWD(1); else if (nvv == 2) SC_LN_BWD(2); else if (nvv == 3) SC_LN_BWD(3);
     else if (nvv == 4) SC_LN_BWD(4); else SC_LN_BWD(8);
 #undef SC_LN_BWD_LEAN
+#undef SC_LN_BWD_LEAN_Q
 #undef SC_LN_BWD
 #undef SC_LN_BWD_Q
 #undef SC_LN_BWD_QG

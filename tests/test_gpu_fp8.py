@@ -261,6 +261,52 @@ def test_layernorm_forward_and_backward_emit_the_e4m3_copy(rows, d):
     assert torch.equal(q8b, want)                       # same bits as torch's e4m3fn rounding of the fp32 result
 
 
+@pytest.mark.parametrize("rows,d,with_t8", [(4500, 1024, True), (300, 1024, False), (600, 768, True)])
+def test_lean_layernorm_backward_emits_the_same_e4m3_copies(rows, d, with_t8, monkeypatch):
+    """The register-lean row body of the LayerNorm backward (round 5: bf16 rows + bf16 gradient stream; default at d = 1024,
+    SC_LN_BWD_LEAN=3 also at d = 768) with the e4m3 copies: the new gradient is formed a third time once the row's scale is
+    known.  Its per-row e4m3 copy is the quantisation of the very fp32 values it wrote (write_f32), its per-tensor copy uses
+    the given scale, the recorded maximum is the tensor's; against the other body: bf16 outputs within one ulp on a few
+    elements, column sums to fp32 rounding.  4500 rows: more blocks than are resident."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.5).bfloat16().cuda()
+    gamma, beta = (1.0 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+    y = torch.empty((rows, d), dtype=torch.bfloat16, device="cuda")
+    m, r = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(x, gamma, beta, y, m, r, rows, d)
+    dy = torch.randn(rows, d, generator=g).bfloat16().cuda()
+    gin = torch.randn(rows, d, generator=g).bfloat16().cuda()
+    res = {}
+    for lean in ("0", "3"):
+        monkeypatch.setenv("SC_LN_BWD_LEAN", lean)
+        dres = torch.full((rows, d), 5.0, device="cuda")
+        gout = torch.empty((rows, d), dtype=torch.bfloat16, device="cuda")
+        dg, db, cs = (torch.empty(d, device="cuda") for _ in range(3))
+        q8 = torch.zeros((rows, d), dtype=torch.uint8, device="cuda"); sinv = torch.zeros(rows, device="cuda")
+        t8 = None
+        if with_t8:
+            t8 = (torch.zeros((rows, d), dtype=torch.uint8, device="cuda"), torch.full((1,), 16.0, device="cuda"),
+                  torch.zeros(64, device="cuda"))
+        ops.layernorm_bwd(dy, x, m, r, gamma, dres, gout, dg, db, cs, rows, d, accumulate=True, g16=True, g_in=gin,
+                          write_f32=True, q8=q8, q8_scale_inv=sinv, t8=t8)
+        torch.cuda.synchronize()
+        s = 1.0 / sinv
+        top = dres.abs().amax(1) * s
+        assert bool((top <= 448.0).all()) and bool((top > 224.0).all())
+        assert torch.equal(q8, (dres * s[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+        if with_t8:
+            assert torch.equal(t8[0], (dres * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+            assert float(t8[2].max()) == float(dres.abs().max())
+        res[lean] = (dres, gout, dg, db, cs)
+    a, b = res["0"], res["3"]
+    torch.testing.assert_close(b[0], a[0], atol=4e-6, rtol=2e-6)
+    diff = (b[1].float() - a[1].float()).abs()
+    assert float((diff > 0).float().mean()) < 0.01 and bool((diff <= 2.0 ** -7 * a[1].float().abs() + 4e-6).all())
+    for p_, q_ in zip(b[2:], a[2:]):
+        torch.testing.assert_close(p_, q_, atol=2e-3, rtol=1e-5)
+
+
 def test_gemm_fp8_dgelu_epilogue_exact_inputs():
     """The data-gradient form (c_proj dgrad: e4m3 residual gradient x e4m3 transposed weight, GELU' epilogue reading the
     bf16 pre-activation): on exactly representable operands the fp8 kernel and the bf16 kernel see the same fp32

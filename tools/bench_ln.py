@@ -50,6 +50,14 @@ cases = [
     ("ln_bwd  bf16 gradient stream", lambda: ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres, gout, dg, db, cs, M, d, accumulate=True, g16=True, g_in=gin, write_f32=False), 10 * E),
     ("ln_bwd  bf16 stream + bf16 rows", lambda: ops.layernorm_bwd(dy, x16, mean, rstd, gamma, dres, gout, dg, db, cs, M, d, accumulate=True, g16=True, g_in=gin, write_f32=False), 8 * E),
 ]
+q8 = torch.empty(M, d, dtype=torch.uint8, device=dev)
+sinv = torch.empty(M, device=dev)
+t8 = (torch.empty(M, d, dtype=torch.uint8, device=dev), torch.full((1,), 16.0, device=dev), torch.zeros(64, device=dev))
+cases += [
+    ("ln_bwd  bf16 + per-row e4m3 copy", lambda: ops.layernorm_bwd(dy, x16, mean, rstd, gamma, dres, gout, dg, db, cs, M, d, accumulate=True, g16=True, g_in=gin, write_f32=False, q8=q8, q8_scale_inv=sinv), 9 * E),
+    ("ln_bwd  bf16 + both e4m3 copies", lambda: ops.layernorm_bwd(dy, x16, mean, rstd, gamma, dres, gout, dg, db, cs, M, d, accumulate=True, g16=True, g_in=gin, write_f32=False, q8=q8, q8_scale_inv=sinv, t8=t8), 10 * E),
+    ("ln_fwd  bf16 rows + per-row e4m3 copy", lambda: ops.layernorm_fwd(x16, gamma, beta, y, mean, rstd, M, d, q8=q8, q8_scale_inv=sinv), 5 * E),
+]
 ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, M, d)
 for name, fn, nbytes in cases:
     us = t(fn)
