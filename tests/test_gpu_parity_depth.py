@@ -136,11 +136,12 @@ def test_vitb16_full_depth_gradients_vs_fp32_oracle(loss_kind):
 # d = 1024 LayerNorm instances sit on this path) + the 6-layer gene transformer, SpatialLoss, B = 8 -- every parameter tensor's
 # gradient against the fp32 oracle, with the reference policy's own autocast (fp32 stream: the quieter yardstick) beside it.
 # Twice the depth of ViT-B/16: the bound on the worst tensor is stated against the yardstick's worst as well.
-def test_vitl14_genetr_full_depth_gradients_vs_fp32_oracle():
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_vitl14_genetr_full_depth_gradients_vs_fp32_oracle(precision):
     data, losses, mc, module, net, optim = _pkg()
     B = 16
     torch.set_num_threads(min(16, os.cpu_count() or 16))
-    n = net.SpatialClipNet("ViT-L-14-genetr", None, n_genes=20000, seed=4)
+    n = net.SpatialClipNet("ViT-L-14-genetr", None, n_genes=20000, seed=4, precision=precision)
     cfg = n.cfg
     assert cfg.vision.layers == 24 and cfg.vision.width == 1024 and cfg.vision.tokens == 257 and cfg.gene.kind == "transformer"
     assert n.residual_stream == "bf16"
@@ -190,10 +191,25 @@ def test_vitl14_genetr_full_depth_gradients_vs_fp32_oracle():
         print(f"[yardstick: reference policy, {mode}, ViT-L/14 + gene transformer] relative L2 vs the fp32 oracle: median "
               f"{yard[stream][0]:.4f}, worst {yard[stream][1]:.4f} {yard[stream][2]}; logit_scale {scalar_err(ga):.3f}; |d loss| {abs(la - loss32):.2e}")
         del ga
-    m = module.SpatialClipLitModule(n, _loss(losses, "spatial"), None, None)
+    m = module.SpatialClipLitModule(
+        n, _loss(losses, "spatial"), functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=1))
     db = {k: t.cuda() for k, t in batch.items()}
+    if precision == "fp8":
+        # delayed scaling: the e4m3 copies of h / dU (and of the weight-gradient operands) use the PREVIOUS step's per-tensor
+        # scales -- prime them with one full training step; the schedule's first step runs at lr = 0, the weights stay put
+        class T:
+            max_steps, max_epochs, estimated_stepping_batches = 100, None, 100
+        m.trainer = T()
+        oc = m.configure_optimizers()
+        loss = m.training_step(db, 0)
+        loss.backward()
+        oc["optimizer"].step(grad_scale=1.0, max_norm=1.0)
+        oc["lr_scheduler"]["scheduler"].step()
+        assert all(torch.equal(p0[k], t.cpu()) for k, t in n.state_dict().items())
+        del loss
     report = []
-    for stream in ("bf16", "fp32"):
+    for stream in (("bf16",) if precision == "fp8" else ("bf16", "fp32")):      # (the e4m3 weight gradients exist on the bf16 stream)
         n.vision.stack.res_stream = stream
         n.store.grad.zero_()
         out = m.model_step(db)
@@ -202,10 +218,17 @@ def test_vitl14_genetr_full_depth_gradients_vs_fp32_oracle():
         grads = {k: n.store.g(k).detach().cpu().double() for k in list(keys) + ["logit_scale"]}
         med, wmax, top = stats(grads)
         dl = abs(float(out["loss"].detach()) - loss32)
-        print(f"[full-depth gradients, ViT-L/14 + gene transformer, spatial, residual stream {stream}] {len(keys)} tensors: relative L2 "
-              f"median {med:.4f}, worst {wmax:.4f} {top}; logit_scale {scalar_err(grads):.3f}; |d loss| {dl:.2e}")
+        print(f"[full-depth gradients, ViT-L/14 + gene transformer, spatial, {precision} operands, residual stream {stream}] {len(keys)} "
+              f"tensors: relative L2 median {med:.4f}, worst {wmax:.4f} {top}; logit_scale {scalar_err(grads):.3f}; |d loss| {dl:.2e}")
         report.append((stream, med, wmax, top, dl))
     assert len(keys) >= 350, len(keys)
+    if precision == "fp8":
+        # e4m3 operands (3 mantissa bits: 2^-4 per element) in six GEMMs of every block, data AND weight gradients, 24 blocks deep:
+        # measured median 26 % / worst 45 % per tensor, the loss within 3e-5.  Stated: the north-star's 1e-3 on the loss, gradients
+        # within 35 % median / 60 % worst of the fp32 oracle's -- what this recipe costs, not a claim of bf16-grade gradients.
+        stream, med, wmax, top, dl = report[0]
+        assert dl <= 1e-3 and med <= 0.35 and wmax <= 0.60, (med, wmax, top, dl)
+        return
     # as at ViT-B/16: both settings against the QUIETER yardstick (the reference policy with the fp32 stream plain functional
     # code keeps); measured at B = 16: reference policy 7.7 % / 26 % (fp32 stream), 12.5 % / 63 % (bf16 stream = the reference as
     # configured); this build 7.3 % / 14.2 % (bf16 stream, the default), 5.5 % / 13.1 % (fp32 stream)
