@@ -339,7 +339,9 @@ def main():
     reducer = comm.make_grad_exchange(n.store)          # None at N = 1; sharded reduce-scatter / all-gather exchange by default
     n.grad_bucket_hook = reducer.bucket_ready if reducer is not None else None
     opt.attach_exchange(reducer)
-    if reducer is not None:       # the exchange that was really built (the sharded route is taken only once its in-place collectives have reproduced an all-reduce on this group)
+    if reducer is None:
+        comm_info["grad_exchange"] = "none (one process)"
+    else:                         # the exchange that was really built (the sharded route is taken only once its in-place collectives have reproduced an all-reduce on this group)
         comm_info["grad_exchange"] = "sharded" if isinstance(reducer, comm.ShardedGradExchange) else "allreduce"
         comm_info["inplace_collectives_verified"] = comm.describe_inplace_check()
         note(f"gradient exchange: {comm_info['grad_exchange']} (in-place collectives verified: {comm_info['inplace_collectives_verified']})")
