@@ -233,6 +233,11 @@ int sc_im2col(const float* images, void* patches, int B, int C, int H, int W, in
 int sc_embed_ln_fwd(const float* patch_out, const float* cls, const float* pos, const float* gamma,
                     const float* beta, float* x, float* mean, float* rstd, int B, int L, int d, float eps,
                     void* stream);
+/* The same with the residual stream starting in bf16 (model.net.residual_stream: bf16 -- under bf16-mixed the reference's ln_pre
+ * output is a bf16 tensor, src/open_clip/transformer.py:26-29,789-791): x_bf16[B*L, d], no fp32 copy and no cast pass. */
+int sc_embed_ln_fwd_x16(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                        const float* beta, void* x_bf16, float* mean, float* rstd, int B, int L, int d, float eps,
+                        void* stream);
 long long sc_embed_ln_bwd_ws_floats(int B, int L, int d);
 int sc_embed_ln_bwd(float* dres, const float* patch_out, const float* cls, const float* pos, const float* mean,
                     const float* rstd, const float* gamma, void* dpatch_bf16, float* dgamma, float* dbeta,

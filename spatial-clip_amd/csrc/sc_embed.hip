@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void im2col_strip_kernel(const float* __restri
 
 // one wave per token row; NV = 16-byte lane slots per row (ceil(d / 256)): a compile-time trip count keeps every load of a
 // row in flight at once (the generic 8-slot loop with run-time predicates ran at 2.5 TB/s, the LayerNorm kernels at 5.7)
-template <int NV>
+template <int NV, bool XB = false>      // XB: the residual stream starts in bf16 (x points at bf16 rows): no fp32 copy + cast pass
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ x,
@@ -117,7 +117,14 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const float* __restri
             f32x4 o;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = (v[i][c] - mu) * rs * g[c] + bb[c];
-            st4(x + (long long)row * d + e * 4, o);
+            if (XB) {
+                bf16x4 ob;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ob[c] = (bf16)o[c];
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(x) + (long long)row * d + e * 4) = ob;
+            } else {
+                st4(x + (long long)row * d + e * 4, o);
+            }
         }
     }
 }
@@ -264,11 +271,34 @@ extern "C" int sc_im2col(const float* images, void* patches, int B, int C, int H
     return 0;
 }
 
+static int embed_ln_fwd_launch(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                               const float* beta, float* x, bool xb, float* mean, float* rstd, int B, int L, int d, float eps,
+                               void* stream);
+
 extern "C" int sc_embed_ln_fwd(const float* patch_out, const float* cls, const float* pos, const float* gamma,
                                const float* beta, float* x, float* mean, float* rstd, int B, int L, int d, float eps,
                                void* stream) {
     SC_CHECK(B > 0 && L > 1 && d > 0 && (d % 4) == 0 && d <= MAXV * 256, "sc_embed_ln_fwd: bad shape B=%d L=%d d=%d", B, L, d);
-#define SC_EMBED_FWD(NV) embed_ln_fwd_kernel<NV><<<(B * L + 3) / 4, 256, 0, (hipStream_t)stream>>>(patch_out, cls, pos, gamma, beta, x, mean, rstd, B, L, d, eps)
+    return embed_ln_fwd_launch(patch_out, cls, pos, gamma, beta, x, false, mean, rstd, B, L, d, eps, stream);
+}
+
+extern "C" int sc_embed_ln_fwd_x16(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                                   const float* beta, void* x_bf16, float* mean, float* rstd, int B, int L, int d, float eps,
+                                   void* stream) {
+    SC_CHECK(B > 0 && L > 1 && d > 0 && (d % 4) == 0 && d <= MAXV * 256 && x_bf16 != nullptr, "sc_embed_ln_fwd_x16: bad shape B=%d L=%d d=%d", B, L, d);
+    return embed_ln_fwd_launch(patch_out, cls, pos, gamma, beta, (float*)x_bf16, true, mean, rstd, B, L, d, eps, stream);
+}
+
+static int embed_ln_fwd_launch(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                               const float* beta, float* x, bool xb, float* mean, float* rstd, int B, int L, int d, float eps,
+                               void* stream) {
+#define SC_EMBED_FWD(NV)                                                                                                          \
+    do {                                                                                                                          \
+        if (xb) embed_ln_fwd_kernel<NV, true><<<(B * L + 3) / 4, 256, 0, (hipStream_t)stream>>>(patch_out, cls, pos, gamma, beta, \
+                                                                                                 x, mean, rstd, B, L, d, eps);     \
+        else embed_ln_fwd_kernel<NV, false><<<(B * L + 3) / 4, 256, 0, (hipStream_t)stream>>>(patch_out, cls, pos, gamma, beta,   \
+                                                                                               x, mean, rstd, B, L, d, eps);     \
+    } while (0)
     switch ((d / 4 + 63) / 64) {
         case 1: SC_EMBED_FWD(1); break;
         case 2: SC_EMBED_FWD(2); break;

@@ -380,9 +380,16 @@ def im2col(images, patches, P: int, ld_out: Optional[int] = None):
 
 
 def embed_ln_fwd(patch_out, cls, pos, gamma, beta, x, mean, rstd, B: int, L: int, d: int, eps: float = 1e-5):
-    check(_lib.lib().sc_embed_ln_fwd(patch_out.data_ptr(), cls.data_ptr(), pos.data_ptr(), gamma.data_ptr(),
-                                     beta.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, L, d, eps,
-                                     _stream()), "sc_embed_ln_fwd")
+    """class token + positional embedding + ln_pre -> the residual stream ``x`` [B*L, d]: fp32, or bf16 (sc_embed_ln_fwd_x16)
+    when the stream is kept in bf16."""
+    if x.dtype == torch.bfloat16:
+        _req(x, torch.bfloat16, "x")
+        fn, what = _lib.lib().sc_embed_ln_fwd_x16, "sc_embed_ln_fwd_x16"
+    else:
+        _req(x, torch.float32, "x")
+        fn, what = _lib.lib().sc_embed_ln_fwd, "sc_embed_ln_fwd"
+    check(fn(patch_out.data_ptr(), cls.data_ptr(), pos.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.data_ptr(),
+             mean.data_ptr(), rstd.data_ptr(), B, L, d, float(eps), _stream()), what)
     return x
 
 

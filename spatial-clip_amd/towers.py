@@ -229,7 +229,7 @@ class TransformerStack:
         XD = BF16 if r16 else F32                     # dtype of the residual stream between the blocks
         epi_res = ops.EPI_BF16_BIAS_RES if r16 else ops.EPI_F32_BIAS_RES
         x = x0
-        if r16:                                       # the stem writes fp32: one cast pass per step
+        if r16 and x0.dtype != BF16:                  # a stem that writes fp32 (the text tower's embedding): one cast pass per step
             x = ops.cast_pad_bf16(x0, bf.get("x0.16", (M, d), BF16), M, d, d)
         # e4m3 MLP weight gradients: only for a pass that will be differentiated, on the bf16 stream (the per-tensor LayerNorm
         # copies exist for bf16 rows), token count a multiple of the 128-token K tile.  With activation recomputation the e4m3
@@ -743,7 +743,10 @@ class PatchTransformerTower:
         bf = self.bufs
         patch_out = bf.get("patch_out", (Mp, d), F32)
         ops.gemm(ops.NT, ops.EPI_F32, patches, s.copies[self._n("conv1.weight")].wf, patch_out, M=Mp, N=d, K=self.kp_pad)
-        x0 = bf.get("x0", (M, d), F32)
+        # the stream's first tensor in the stream's own precision: with the bf16 stream ln_pre writes bf16 (as the reference's does
+        # under bf16-mixed) instead of an fp32 copy that a cast pass then halves (310 MB of traffic per step at ViT-B/16)
+        r16 = self.stack.res16_ok and _res_stream_bf16(self.stack.res_stream) and os.environ.get("SC_STEM_BF16", "1") != "0"
+        x0 = bf.get("x0.16", (M, d), BF16) if r16 else bf.get("x0", (M, d), F32)
         ops.embed_ln_fwd(patch_out, s.p(self._n("class_embedding")), s.p(self._n("positional_embedding")),
                          s.p(self._n("ln_pre.weight")), s.p(self._n("ln_pre.bias")), x0,
                          bf.get("m_pre", (M,), F32), bf.get("r_pre", (M,), F32), B, L, d)

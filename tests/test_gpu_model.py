@@ -651,6 +651,30 @@ def test_adamw_behind_the_next_forward_is_bit_identical(monkeypatch, overlap):
     assert torch.equal(res["0"][2], res["1"][2]) and torch.equal(res["0"][3], res["1"][3]) and torch.equal(res["0"][4], res["1"][4])
 
 
+def test_stem_writes_the_bf16_residual_stream_directly(monkeypatch):
+    """With the bf16 residual stream the patch towers' ln_pre writes bf16 rows (sc_embed_ln_fwd_x16, round 5) instead of fp32 rows
+    that a cast pass halves: same rounding of the same fp32 values, so loss, features and every gradient are bit-identical
+    (SC_STEM_BF16=0 = the two-pass form) -- ViT + gene transformer (both are patch towers)."""
+    data, losses, mc, module, net, optim = _pkg()
+    cfg, _ = genetr_cfgs(width=128, head_width=64, layers=2, image=48, patch=16, glayers=2, gwidth=64, ghead=32)
+    B = 16
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=7)
+    perturb(n)
+    m = module.SpatialClipLitModule(n, losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True), None, None)
+    db = {k: v.cuda() for k, v in data.synthetic_batch(B, 48, cfg.gene.n_genes, K=4, step=0).items()}
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SC_STEM_BF16", mode)
+        n.store.grad.zero_()
+        out = m.model_step(db)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res[mode] = (float(out["loss"].detach()), out["image_features"].detach().clone(), out["text_features"].detach().clone(),
+                     n.store.grad.detach().clone())
+    assert res["0"][0] == res["1"][0]
+    assert all(torch.equal(a, b) for a, b in zip(res["0"][1:], res["1"][1:]))
+
+
 def test_last_block_projects_q_for_the_class_tokens_only(monkeypatch):
     """The last ViT block's attention output is read for the class token alone (pool 'tok'), so q of the other rows is dead
     work: by default the block projects K | V for every token and Q for the B class tokens, and its data / weight gradients
