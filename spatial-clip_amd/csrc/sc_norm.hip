@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dy / x instead of behind the two wave reductions (one exposed memory round trip per row less; gamma is re-read per row from
 // L1 so that the kernel stays at 128 VGPRs = 4 waves per SIMD).
 template <int NV, bool Q8, bool XB = false, bool GIN = false, bool LEAN = false>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long long lddy,
+__global__ __launch_bounds__(256, (LEAN && NV == 3 && !Q8) ? 5 : 1) void ln_bwd_kernel(const bf16* __restrict__ dy, long long lddy,
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dres,
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      long long ldgin = 0, int write_f32 = 1, const LnT8 t8 = LnT8(),
                                                      int nominal_blocks = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: row pointers live in SGPRs
     const int nv = d >> 2;
     f32x4 ag[NV], ab[NV], ac[NV], gm[GIN ? 1 : NV];
 #pragma unroll
@@ -712,10 +713,16 @@ extern "C" int sc_layernorm_fwd_x16_t8(const void* x_bf16, long long ldx, const 
                          true, t8);
 }
 
+// Partial-sum slots of a LayerNorm backward launch = its nominal block count, a function of the shape alone (the finalising
+// pass may run from another entry point).  Rows up to 768 wide fit FIVE blocks per CU (<= 96 VGPRs, 27 KiB of LDS): 1280.
+static int ln_nominal_blocks(int rows, int d) {
+    const int cap = d <= 768 ? 1280 : 1024;
+    const int nblk = (rows + 3) / 4;
+    return nblk > cap ? cap : nblk;
+}
+
 extern "C" long long sc_layernorm_bwd_ws_floats(int rows, int d) {
-    int nblk = (rows + 3) / 4;
-    if (nblk > 1024) nblk = 1024;
-    return (long long)nblk * 3 * d;
+    return (long long)ln_nominal_blocks(rows, d) * 3 * d;
 }
 
 // The row loop of the LayerNorm kernels is persistent (a wave walks rows with a grid stride), so a grid larger than what is
@@ -754,8 +761,7 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
     SC_CHECK(ws != nullptr, "sc_layernorm_bwd: workspace required");
     SC_CHECK(d8 == nullptr || (scale_inv != nullptr && (ldd8 % 4) == 0 && ldd8 >= d),
              "sc_layernorm_bwd_q8: fp8 output needs scale_inv and a row stride that is a multiple of 4 (ldd8=%lld)", ldd8);
-    int nblk = (rows + 3) / 4;
-    if (nblk > 1024) nblk = 1024;
+    const int nblk = ln_nominal_blocks(rows, d);
     const size_t lds = (size_t)3 * 3 * d * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int nvv = (d / 4 + 63) / 64;
@@ -779,10 +785,15 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
         if (xb) { if (d8) SC_LN_BWD_Q(NV, true, true); else SC_LN_BWD_Q(NV, false, true); }                             \
         else { if (d8) SC_LN_BWD_Q(NV, true, false); else SC_LN_BWD_Q(NV, false, false); }                              \
     } while (0)
-    // lean row body (bf16 rows + bf16 gradient stream, no e4m3 copies): d = 1024 by default; SC_LN_BWD_LEAN=0 off, =3 also d = 768
+    // lean row body (bf16 rows + bf16 gradient stream).  With the wave index in an SGPR (row pointers are scalar) the plain body
+    // needs 128 VGPRs at d = 1024 = four waves per SIMD by itself and is the faster one there (111 vs 117 us); the lean body stays
+    // the default for the QUANTISING instances at d = 1024 (130 VGPRs otherwise; 171 vs 209 us with both e4m3 copies).
+    // SC_LN_BWD_LEAN=0: never; =4: also without e4m3 copies at d = 1024; =3: everywhere it exists (d = 768 too: no gain measured).
     const char* lean_env = getenv("SC_LN_BWD_LEAN");      // read per call: the tests run both bodies in one process
-    const int lean_mode = lean_env ? atoi(lean_env) : 4;
-    const bool lean_ok = xb && gin != nullptr && accumulate > 0 && lean_mode != 0;
+    const int lean_mode = lean_env ? atoi(lean_env) : -1;
+    const bool lean_base = xb && gin != nullptr && accumulate > 0 && lean_mode != 0;
+    const bool lean4 = lean_base && nvv == 4 && (d8 != nullptr || lean_mode == 4 || lean_mode == 3);
+    const bool lean3 = lean_base && nvv == 3 && lean_mode == 3;
 #define SC_LN_BWD_LEAN_Q(NV, Q)                                                                                         \
     do {                                                                                                                \
         if (lds > 48 * 1024)                                                                                            \
@@ -795,8 +806,8 @@ static int ln_bwd_launch(const void* dy, long long lddy, const float* x, long lo
             accumulate, (unsigned char*)d8, ldd8, scale_inv, (const bf16*)gin, ldgin, write_f32, t8, nblk);             \
     } while (0)
 #define SC_LN_BWD_LEAN(NV) do { if (d8) SC_LN_BWD_LEAN_Q(NV, true); else SC_LN_BWD_LEAN_Q(NV, false); } while (0)
-    if (lean_ok && nvv == 4) SC_LN_BWD_LEAN(4);
-    else if (lean_ok && nvv == 3 && lean_mode == 3) SC_LN_BWD_LEAN(3);
+    if (lean4) SC_LN_BWD_LEAN(4);
+    else if (lean3) SC_LN_BWD_LEAN(3);
     else if (nvv <= 1) SC_LN_BWD(1); else if (nvv == 2) SC_LN_BWD(2); else if (nvv == 3) SC_LN_BWD(3);
     else if (nvv == 4) SC_LN_BWD(4); else SC_LN_BWD(8);
 #undef SC_LN_BWD_LEAN
@@ -873,8 +884,7 @@ extern "C" int sc_layernorm_bwd_reduce(const float* ws, int rows, int d, float* 
                                        void* stream) {
     SC_CHECK(rows > 0 && d > 0 && ws != nullptr && dgamma != nullptr && dbeta != nullptr,
              "sc_layernorm_bwd_reduce: bad arguments rows=%d d=%d", rows, d);
-    int nblk = (rows + 3) / 4;
-    if (nblk > 1024) nblk = 1024;
+    const int nblk = ln_nominal_blocks(rows, d);
     colvec_finalize_kernel<<<(3 * d + 63) / 64, 1024, 0, (hipStream_t)stream>>>(ws, nblk, 3, d, dgamma, dbeta, colsum);
     SC_LAUNCH_CHECK();
     return 0;

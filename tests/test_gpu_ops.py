@@ -258,14 +258,28 @@ def test_layernorm_bf16_rows_and_bf16_gradient_stream(rows, d):
     # fp32 buffer form on bf16 rows == on fp32 rows
     a = bwd(x16, dres0=gin.float(), accumulate=True)
     b = bwd(x16.float(), dres0=gin.float(), accumulate=True)
-    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    assert all(torch.equal(p, q) for p, q in zip(a[:2], b[:2]))
+    if rows <= 2000:
+        assert all(torch.equal(p, q) for p, q in zip(a[2:], b[2:]))
+    else:
+        for p_, q_ in zip(a[2:], b[2:]):
+            torch.testing.assert_close(p_, q_, atol=2e-3, rtol=1e-5)
     # bf16 stream (fp32 rows and bf16 rows): same outgoing gradient and column sums; the fp32 buffer only on request
     marker = torch.full((rows, d), 11.0, device=dev)
     os.environ["SC_LN_BWD_LEAN"] = "0"              # (d = 1024 on bf16 rows has a second, register-lean row body: below)
+
+    def same_sums(ps, qs):
+        # column sums: partial sums per BLOCK, and with more rows than resident blocks the instantiations (different register
+        # counts, different resident grids) partition the rows differently -- same bits only while one block takes four rows
+        if rows <= 2000:
+            return all(torch.equal(p, q) for p, q in zip(ps, qs))
+        for p, q in zip(ps, qs):
+            torch.testing.assert_close(p, q, atol=2e-3, rtol=1e-5)
+        return True
     try:
         for xx in (x16.float(), x16):
             c = bwd(xx, dres0=marker, accumulate=True, g16=True, g_in=gin, write_f32=False)
-            assert torch.equal(c[0], marker) and torch.equal(c[1], a[1]) and all(torch.equal(p, q) for p, q in zip(c[2:], a[2:]))
+            assert torch.equal(c[0], marker) and torch.equal(c[1], a[1]) and same_sums(c[2:], a[2:])
             c = bwd(xx, dres0=marker, accumulate=True, g16=True, g_in=gin, write_f32=True)
             assert torch.equal(c[0], a[0]) and torch.equal(c[1], a[1])
     finally:
