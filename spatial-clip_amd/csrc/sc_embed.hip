@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(float* __restrict__ d
                                                            const float* __restrict__ gamma, bf16* __restrict__ dpatch,
                                                            float* __restrict__ partial, int B, int L, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: row pointers in SGPRs
     const int nv = d >> 2;
     const int rows = B * L;
     f32x4 ag[NV], ab[NV], gm[NV];
