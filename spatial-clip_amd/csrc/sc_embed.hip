@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const float* __restri
                                                            float* __restrict__ mean, float* __restrict__ rstd, int B,
                                                            int L, int d, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= B * L) return;
     const int b = row / L, tkn = row - b * L;
     const float* src = tkn == 0 ? cls : patch + ((long long)b * (L - 1) + (tkn - 1)) * d;

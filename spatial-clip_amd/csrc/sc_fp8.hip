@@ -30,7 +30,7 @@ template <bool F32>
 __global__ __launch_bounds__(256) void quantize_rows_kernel(const void* __restrict__ src, long long ld_src, int rows, int cols,
                                                             unsigned char* __restrict__ dst, long long ld_dst,
                                                             float* __restrict__ scale_inv, float fixed_scale) {
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* sf = reinterpret_cast<const float*>(src) + (long long)row * ld_src;
     const bf16* sb = reinterpret_cast<const bf16*>(src) + (long long)row * ld_src;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void quantize_rows_batched_kernel(const long l
     const bool f32 = dsc[1] != 0;
     const long long ld_src = dsc[2], ld_dst = dsc[6];
     const int rows = (int)dsc[3], cols = (int)dsc[4];
-    const int row = (b - block_prefix[lo]) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = (b - block_prefix[lo]) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* sf = reinterpret_cast<const float*>(dsc[0]) + (long long)row * ld_src;
     const bf16* sb = reinterpret_cast<const bf16*>(dsc[0]) + (long long)row * ld_src;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     // Rows are walked LAST ROW FIRST: the producer in front (a GEMM walking its tiles upwards) wrote the high rows last, so
     // they are the ones still in the 256-MB Infinity Cache; and the rows this kernel writes last are the low ones the next
     // GEMM reads first.  Same-box A/B of the whole step: -0.19 ms (profiles/r03_ln_row_order_ab.txt).
-    const int row = rows - 1 - (blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int row = rows - 1 - (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));     // wave-uniform: scalar row pointers
     if (row < 0) return;
     const float* xr = x + (long long)row * ldx;
     const bf16* xrb = reinterpret_cast<const bf16*>(x) + (long long)row * ldx;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
                                                          bf16* __restrict__ ybf, float* __restrict__ inv, int rows,
                                                          int d) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (long long)row * d;
     float s = 0.f;
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ inv, bf16* __restrict__ dx,
                                                          int rows, int d) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= rows) return;
     const float* yr = y + (long long)row * d;
     const float* gr = dy + (long long)row * d;
