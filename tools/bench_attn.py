@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import spatial_clip_amd  # noqa
 from spatial_clip_amd import ops
 
-B, L, H, dh = int(os.environ.get("B", 256)), 197, 12, 64
+B, L, H, dh = int(os.environ.get("B", 256)), int(os.environ.get("L", 197)), int(os.environ.get("H", 12)), 64      # B=3072 H=1: the same bytes head-major
 d = H * dh
 g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B * L, 3 * d, device="cuda", generator=g).bfloat16()
