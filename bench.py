@@ -35,6 +35,10 @@ def flops_per_pair(cfg, G: int) -> float:
         fwd += g.layers * (2.0 * gl * gd * 3 * gd + 2 * (2.0 * gl * gl * gd) + 2.0 * gl * gd * gd + 2 * (2.0 * gl * gd * gm))
     elif cfg.gene is not None:
         fwd += 2.0 * cfg.gene.n_genes * cfg.gene.hidden + 2.0 * cfg.gene.hidden * D
+    elif cfg.text is not None:      # the reference's CLIP text tower (+5.960 GFLOP forward at d = 512)
+        t = cfg.text
+        tl, td, tm = t.context_length, t.width, int(t.width * t.mlp_ratio)
+        fwd += t.layers * (2.0 * tl * td * 3 * td + 2 * (2.0 * tl * tl * td) + 2.0 * tl * td * td + 2 * (2.0 * tl * td * tm)) + 2.0 * td * D
     fwd += 4.0 * G * D
     return 3.0 * fwd
 
@@ -82,9 +86,24 @@ def cpu_model_string() -> str:
 def _oracle_cfg(cfg):
     from oracle import spatial_clip_oracle as O
     v = cfg.vision
-    g = cfg.gene
-    return O.ModelCfg(cfg.embed_dim, O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width), None,
+    g, t = cfg.gene, cfg.text
+    vis = O.VisionCfg(v.image_size, v.patch_size, v.width, v.layers, v.head_width)
+    if g is None:               # the reference's own pairing: CLIP text tower on token ids
+        return O.ModelCfg(cfg.embed_dim, vis, O.TextCfg(t.context_length, t.vocab_size, t.width, t.heads, t.layers, t.mlp_ratio),
+                          None, quick_gelu=bool(getattr(cfg, "quick_gelu", False)))
+    return O.ModelCfg(cfg.embed_dim, vis, None,
                       O.GeneCfg(g.n_genes, g.hidden, g.kind, g.patch, g.width, g.layers, g.head_width, g.mlp_ratio))
+
+
+def make_batch(cfg, B, n_genes, step=0, rank=0, world=1, rates=None):
+    """One synthetic batch of the reference's batch contract for this model: gene matrix in the ``texts`` slot for the gene
+    towers, BPE-shaped token ids for the reference's text tower (data.synthetic_captions)."""
+    from spatial_clip_amd import data
+    b = data.synthetic_batch(B, cfg.vision.image_size, n_genes if cfg.gene is not None else 64, 8, step, rank, world,
+                             rates if cfg.gene is not None else None)
+    if cfg.gene is None:
+        b["texts"] = data.synthetic_captions(B, cfg.text.context_length, cfg.text.vocab_size, seed=4321 + 1000 * step + rank)
+    return b
 
 
 def cpu_baseline_leg(model_name: str, n_genes: int, B: int, steps: int = 3, loss: str = "clip"):
@@ -102,7 +121,7 @@ def cpu_baseline_leg(model_name: str, n_genes: int, B: int, steps: int = 3, loss
     rates = data.make_gene_rates(n_genes)
     times = []
     for s in range(steps + 1):
-        batch = data.synthetic_batch(B, cfg.vision.image_size, n_genes, 8, s, gene_rates=rates)
+        batch = make_batch(cfg, B, n_genes, s, rates=rates)
         t0 = time.time()
         tr.training_step(batch)
         times.append(time.time() - t0)
@@ -112,11 +131,11 @@ def cpu_baseline_leg(model_name: str, n_genes: int, B: int, steps: int = 3, loss
             "pairs_per_s_median": round(B / timed[len(timed) // 2], 3), "step_s": [round(t, 3) for t in times]}
 
 
-def cpu_baseline(model_name: str, n_genes: int):
+def cpu_baseline(model_name: str, n_genes: int, B: int = 32):
     """Reported baseline only (SURVEY.md 8d / BASELINE.md section 4): the oracle restatement of the identical
     training_step on the GPU box's host cores, cfg [0] (ViT-Ti/16 + 2-layer gene-MLP, B = 8) and the bench model at a
     reduced batch (B = 32), 1 warm-up + 3 timed steps each."""
-    legs = [cpu_baseline_leg("ViT-Ti-16-gene", n_genes, 8), cpu_baseline_leg(model_name, n_genes, 32)]
+    legs = [cpu_baseline_leg("ViT-Ti-16-gene", n_genes, 8), cpu_baseline_leg(model_name, n_genes, min(32, B))]
     head = legs[1]
     return {"value": head["pairs_per_s_best"], "unit": "pairs/s", "cores": host_cpu_share(), "kind": "port",
             "cpu_model": cpu_model_string(),
@@ -350,7 +369,7 @@ def main():
     rates = data.make_gene_rates(args.n_genes)
     batches = []
     for s in range(2):          # synthetic inputs resident in HBM before the timed region
-        b = data.synthetic_batch(B, cfg.vision.image_size, args.n_genes, 8, s, rank, world, rates)
+        b = make_batch(cfg, B, args.n_genes, s, rank, world, rates)
         batches.append({k: v.cuda() for k, v in b.items()})
 
     def step(i):
@@ -376,7 +395,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_loss_delta:
         init_sd = n.state_dict()
         note("loss delta vs the fp32 oracle at the initial weights (oracle forward on the host)")
-        delta_init = loss_delta_vs_oracle(m, n, cfg, data.synthetic_batch(B, cfg.vision.image_size, args.n_genes, 8, 0, 0, 1, rates),
+        delta_init = loss_delta_vs_oracle(m, n, cfg, make_batch(cfg, B, args.n_genes, 0, 0, 1, rates),
                                           args.loss, args.dtype, "initial weights, benchmark batch 0")
         note(f"init-point loss delta {delta_init['loss_delta_vs_oracle']:.2e}, max feature delta "
              f"{delta_init['max_abs_feature_delta']:.2e} (bound {delta_init['tolerance']:g})")
@@ -523,8 +542,7 @@ def main():
         for i in range(PARITY_TRAINED_STEPS):
             step(i)
         torch.cuda.synchronize()
-        delta = loss_delta_vs_oracle(m, n, cfg, data.synthetic_batch(B, cfg.vision.image_size, args.n_genes, 8, 0, 0, 1,
-                                                                     rates), args.loss, args.dtype,
+        delta = loss_delta_vs_oracle(m, n, cfg, make_batch(cfg, B, args.n_genes, 0, 0, 1, rates), args.loss, args.dtype,
                                      f"initial weights + {PARITY_TRAINED_STEPS} optimiser steps over the two resident batches, "
                                      "benchmark batch 0", trained=True)
         note(f"trained point: loss delta {delta['loss_delta_vs_oracle']:.2e}, max feature delta {delta['max_abs_feature_delta']:.2e} "
@@ -533,7 +551,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle baseline (bounded sample)")
-            cpu = cpu_baseline(args.model, args.n_genes)
+            cpu = cpu_baseline(args.model, args.n_genes, B)
             note("cpu baseline done")
         out = {"metric": "tile-gene pairs/sec (train step)", "value": round(value, 2), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_steps": setup_steps,
@@ -542,6 +560,8 @@ def main():
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"{args.model} image tower + " + (
+                          f"CLIP text tower(vocab {cfg.text.vocab_size}, {cfg.text.layers} x {cfg.text.width}, context "
+                          f"{cfg.text.context_length}, embed {cfg.embed_dim}), " if cfg.gene is None else
                           f"gene-MLP({args.n_genes}->{cfg.gene.hidden}->{cfg.embed_dim}), " if cfg.gene.kind == "mlp" else
                           f"{cfg.gene.layers}-layer gene transformer({args.n_genes} genes -> {cfg.gene.tokens} tokens x "
                           f"{cfg.gene.width}, embed {cfg.embed_dim}), ") + (

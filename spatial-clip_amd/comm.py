@@ -90,10 +90,13 @@ def describe_inplace_check() -> Optional[bool]:
 
 
 def grad_exchange_mode() -> str:
-    """SC_GRAD_EXCHANGE = 'sharded' (default: per-bucket reduce-scatter -> AdamW on this rank's 1/W of every bucket ->
-    all-gather of the refreshed weights) or 'allreduce' (rounds 1-4: bucketed SUM all-reduce of the flat
-    gradient, AdamW replicated on every rank).  Same weights either way (tests/test_gpu_ddp.py)."""
-    return os.environ.get("SC_GRAD_EXCHANGE", "sharded")
+    """SC_GRAD_EXCHANGE = 'allreduce' (default: bucketed SUM all-reduce of the flat gradient overlapped with backward, AdamW
+    replicated on every rank -- the reference's DDP shape) or 'sharded' (opt-in: per-bucket reduce-scatter -> AdamW on this
+    rank's 1/W of every bucket -> all-gather of the refreshed weights behind the next forward).  Same weights
+    either way (tests/test_gpu_ddp.py).  The sharded route was the default in round 5; it has never run on more than one real
+    RCCL rank (no multi-GPU box is available to this build), so the route that ships by default is the one whose collective
+    -- a plain out-of-place-free all-reduce -- carries no aliasing assumption (advisor, round 5)."""
+    return os.environ.get("SC_GRAD_EXCHANGE", "allreduce")
 
 
 def is_dist() -> bool:
@@ -677,44 +680,73 @@ class ShardedGradExchange:
 _INPLACE_CHECK: dict = {}
 
 
+INPLACE_CHECK_FLOATS = 4 * 1024 * 1024        # per rank piece of the start-up check (16 MB): a real bucket piece, not a toy
+
+
 def inplace_collectives_verified(device) -> bool:
     """Start-up check of the two IN-PLACE collectives the sharded exchange relies on (reduce-scatter whose output is the rank's
-    piece of its input; all-gather whose input is the rank's piece of its output), on a small scratch buffer against a plain
-    SUM all-reduce.  Collective: every rank calls it; the verdict is the MIN over ranks, so all ranks take the same route.
-    Runs once per process group and device; the result is in ``describe()``."""
+    piece of its input; all-gather whose input is the rank's piece of its output) against a plain SUM all-reduce, issued THE WAY
+    THE STEP ISSUES THEM (advisor, round 5): bucket-sized buffers (W pieces of ``INPLACE_CHECK_FLOATS``), the reduce-scatter as
+    an async call from the current stream with a producer kernel right in front of it, the all-gather on the communication
+    stream (``streams.comm_stream``) behind an event, as ``ShardedGradExchange._reduce_scatter`` / ``gather_bucket`` do.  Any
+    exception -- not only RuntimeError -- and any mismatch sends every rank to the all-reduce route.  Collective: every rank
+    calls it; the verdict is the MIN over ranks.  Runs once per process group and device; the result is in ``describe()``."""
     key = (dist.get_backend(), str(device))
     if key in _INPLACE_CHECK:
         return _INPLACE_CHECK[key]
     rank, W = world()
-    n = 256 * W
+    on_gpu = torch.device(device).type == "cuda"
+    c = INPLACE_CHECK_FLOATS if on_gpu else 256
+    n = c * W
     base = (torch.arange(n, dtype=torch.float32, device=device) % 97) * 0.25
     mine = base * float(rank + 1) + float(rank)
     want = mine.clone()
     dist.all_reduce(want, op=dist.ReduceOp.SUM)
-    c = n // W
     a, b = rank * c, (rank + 1) * c
     ok = True
     try:
-        buf = mine.clone()
+        buf = torch.empty_like(mine)
+        buf.copy_(mine)                         # the producer kernel, on the current stream, right in front of the collective
         if _native is not None and buf.is_cuda:
             cur = torch.cuda.current_stream(buf.device)
-            _native.reduce_scatter(buf, buf[a:b], cur)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            _native.stream.wait_event(ready)
+            _native.reduce_scatter(buf, buf[a:b], _native.stream)
+            done = torch.cuda.Event()
+            done.record(_native.stream)
+            cur.wait_event(done)
         elif dist.get_backend() == "gloo":
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True).wait()
         else:
-            dist.reduce_scatter_tensor(buf[a:b], buf, op=dist.ReduceOp.SUM)
+            dist.reduce_scatter_tensor(buf[a:b], buf, op=dist.ReduceOp.SUM, async_op=True).wait()
         ok = ok and bool(torch.equal(buf[a:b], want[a:b]))
         buf = torch.full_like(mine, -1.0)
         buf[a:b] = want[a:b]
-        if _native is not None and buf.is_cuda:
-            _native.all_gather(buf[a:b], buf, torch.cuda.current_stream(buf.device))
+        if buf.is_cuda:
+            from . import streams
+            cur = torch.cuda.current_stream(buf.device)
+            cs = streams.comm_stream(buf.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            cs.wait_event(ready)
+            with torch.cuda.stream(cs):
+                if _native is not None:
+                    _native.all_gather(buf[a:b], buf, cs)
+                elif dist.get_backend() == "gloo":
+                    dist.all_gather_into_tensor(buf, buf[a:b].clone())
+                else:
+                    dist.all_gather_into_tensor(buf, buf[a:b], async_op=True).wait()
+                done = torch.cuda.Event()
+                done.record(cs)
+            cur.wait_event(done)
         elif dist.get_backend() == "gloo":
             dist.all_gather_into_tensor(buf, buf[a:b].clone())
         else:
             dist.all_gather_into_tensor(buf, buf[a:b])
         ok = ok and bool(torch.equal(buf, want))
-    except RuntimeError as e:               # a backend that refuses aliased buffers says so here, not in the first training step
-        sys.stderr.write(f"[spatial_clip_amd.comm] rank {rank}: in-place collective refused: {e}\n")
+    except Exception as e:                  # a backend that refuses aliased buffers says so here, not in the first training step
+        sys.stderr.write(f"[spatial_clip_amd.comm] rank {rank}: in-place collective refused: {type(e).__name__}: {e}\n")
         ok = False
     flag = torch.tensor([1.0 if ok else 0.0], device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -723,13 +755,22 @@ def inplace_collectives_verified(device) -> bool:
 
 
 def make_grad_exchange(store, bucket_floats: int = 16 * 1024 * 1024):
-    """The gradient exchange of this process group: ``ShardedGradExchange`` (default) or the rounds-1-4
-    ``GradBucketReducer`` (SC_GRAD_EXCHANGE=allreduce); None without a group.  The sharded route is taken only after its two
-    in-place collectives have reproduced a plain all-reduce on this group (``inplace_collectives_verified``); otherwise every
-    rank says so on stderr and takes the all-reduce route -- same weights, the reference's DDP shape."""
+    """The gradient exchange of this process group: ``GradBucketReducer`` (default: bucketed all-reduce + replicated AdamW, the
+    reference's DDP shape) or, with SC_GRAD_EXCHANGE=sharded, ``ShardedGradExchange``; None without a group.  The sharded route
+    is taken only (a) when the parameter store was padded for this world size -- a store built before ``comm.init_from_env``
+    (a library user) is not: that warns and takes the all-reduce route instead of raising -- and (b) after its two in-place
+    collectives have reproduced a plain all-reduce on this group (``inplace_collectives_verified``); otherwise every rank says so
+    on stderr and takes the all-reduce route -- same weights."""
     if not is_dist():
         return None
-    if grad_exchange_mode() == "allreduce":
+    if grad_exchange_mode() != "sharded":
+        return GradBucketReducer(store.grad, bucket_floats)
+    _, W = world()
+    if store.total % (64 * W):
+        sys.stderr.write(f"[spatial_clip_amd.comm] the parameter store ({store.total} floats) was built before the process group and is "
+                         f"not padded for {W} ranks: gradient exchange falls back to bucketed all-reduce + replicated AdamW "
+                         "(build the model after comm.init_from_env() for the sharded route)\n")
+        os.environ["SC_GRAD_EXCHANGE"] = "allreduce"
         return GradBucketReducer(store.grad, bucket_floats)
     if not inplace_collectives_verified(store.grad.device):
         sys.stderr.write("[spatial_clip_amd.comm] in-place reduce-scatter / all-gather did not reproduce the all-reduce on this "

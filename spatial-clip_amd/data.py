@@ -43,6 +43,21 @@ def synthetic_batch(B: int, image_size: int, n_genes: int, K: int = 8, step: int
             "neighbor_tile_ids": nb, "neighbor_alphas": al}
 
 
+def synthetic_captions(B: int, context_length: int = 77, vocab_size: int = 49408, seed: int = 0) -> torch.Tensor:
+    """int64 [B, context_length] token ids shaped like the reference tokenizer's output (src/open_clip/tokenizer.py:
+    <start_of_text> = vocab - 2, words, <end_of_text> = vocab - 1 -- the largest id, which CLIP.encode_text pools at by argmax --
+    zero padding).  Ragged lengths: every other row fills the context (a 50-gene sentence of the data pipeline usually does)."""
+    g = torch.Generator().manual_seed(seed)
+    sot, eot = vocab_size - 2, vocab_size - 1
+    t = torch.zeros(B, context_length, dtype=torch.int64)
+    for b in range(B):
+        n = context_length - 2 if b % 2 == 0 else int(torch.randint(3, context_length - 2, (1,), generator=g))
+        t[b, 0] = sot
+        t[b, 1:1 + n] = torch.randint(1, sot, (n,), generator=g)
+        t[b, 1 + n] = eot
+    return t
+
+
 class SyntheticSpatialDataModule:
     """Constructor kwargs of ``SpatialClipDataModule`` (spatial_datamodule.py:21-31) plus the synthetic knobs."""
 

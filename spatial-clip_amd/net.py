@@ -85,7 +85,7 @@ def resize_pos_embed(state_dict: Dict[str, torch.Tensor], grid_size, interpolati
 
 
 def resize_text_pos_embed(state_dict: Dict[str, torch.Tensor], num_pos: int, interpolation: str = "linear",
-                          antialias: bool = False) -> None:
+                          antialias: bool = False, model_width: Optional[int] = None) -> None:
     """Resample the text tower's positional embedding of a checkpoint to this model's context length when they differ
     (``src/open_clip/model.py:826-860``, called from ``load_checkpoint`` right after ``resize_pos_embed``,
     factory.py:220-221): 1-D linear interpolation along the position axis, ``align_corners=False``, width unchanged.
@@ -97,28 +97,40 @@ def resize_text_pos_embed(state_dict: Dict[str, torch.Tensor], num_pos: int, int
     old_num, width = old.shape
     if old_num == int(num_pos):
         return
+    if model_width is not None and int(model_width) != int(width):      # model.py:840: 'text pos_embed width changed!'
+        raise AssertionError(f"text pos_embed width changed: checkpoint {width}, model {model_width}")
     x = old.float().reshape(1, old_num, width).permute(0, 2, 1)
     x = torch.nn.functional.interpolate(x, size=int(num_pos), mode=interpolation, antialias=antialias, align_corners=False)
     state_dict[key] = x.permute(0, 2, 1)[0].to(old.dtype)
 
 
-def read_checkpoint_file(path: str) -> Dict[str, Any]:
+def read_checkpoint_file(path: str, unsafe_pickle: Optional[bool] = None) -> Dict[str, Any]:
     """What ``open_clip.factory.load_state_dict`` accepts (src/open_clip/factory.py:153-178): a ``.safetensors`` file
     (``safetensors.torch.load_file``), a pickled state_dict / training checkpoint (``{'state_dict': ...}``), or a TorchScript
-    archive (OpenAI's released ``.pt`` files: ``state_dict()`` minus the three bookkeeping buffers).  Host tensors."""
+    archive (OpenAI's released ``.pt`` files: ``state_dict()`` minus the three bookkeeping buffers).  Host tensors.
+
+    Like the reference, pickles are read with ``weights_only=True`` and nothing else by default: a file that pickles more than
+    tensors (a Lightning checkpoint with hyper-parameters / callbacks) is refused with the original error unless the caller
+    opts in -- ``unsafe_pickle=True`` or ``SC_UNSAFE_PICKLE=1`` -- because unpickling arbitrary objects executes code, and
+    ``pretrained`` is typically a downloaded file (advisor, round 5).  ``Trainer.load_checkpoint`` (the user's own resume
+    files) opts in itself."""
     if str(path).endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(path, device="cpu")
+    if unsafe_pickle is None:
+        unsafe_pickle = os.environ.get("SC_UNSAFE_PICKLE", "0") == "1"
     try:
         ckpt = torch.load(path, map_location="cpu", weights_only=True)
     except Exception as first:
         try:        # TorchScript archives are zip files torch.load(weights_only=True) refuses; torch.jit.load reads them
             ckpt = torch.jit.load(path, map_location="cpu")
         except Exception:
-            try:    # checkpoints that pickle more than tensors (Lightning: hyper-parameters, callbacks)
-                ckpt = torch.load(path, map_location="cpu", weights_only=False)
-            except Exception:
-                raise first
+            if not unsafe_pickle:
+                raise RuntimeError(
+                    f"{path}: not a weights-only pickle, a .safetensors file or a TorchScript archive ({type(first).__name__}: "
+                    f"{first}).  If this is a TRUSTED checkpoint that pickles more than tensors (e.g. a Lightning file), pass "
+                    "unsafe_pickle=True or set SC_UNSAFE_PICKLE=1") from first
+            ckpt = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(ckpt, torch.jit.ScriptModule):
         sd = dict(ckpt.state_dict())
         for k in ("input_resolution", "context_length", "vocab_size"):
@@ -150,7 +162,9 @@ class _ClipFacade:
 
     @property
     def logit_scale(self) -> torch.nn.Parameter:
-        return self._net.store.params["logit_scale"]
+        st = self._net.store
+        st.wait_names(["logit_scale"])      # an update may still be running behind the forward (communication stream)
+        return st.params["logit_scale"]
 
     logit_bias = None
 
@@ -316,7 +330,7 @@ class SpatialClipNet(torch.nn.Module):
             g = self.cfg.vision.image_size // self.cfg.vision.patch_size
             resize_pos_embed(sd, (g, g))
         if self.cfg.text is not None:           # factory.py:221: the text positions follow the model's context length
-            resize_text_pos_embed(sd, self.cfg.text.context_length)
+            resize_text_pos_embed(sd, self.cfg.text.context_length, model_width=self.cfg.text.width)
         ls = sd.get("logit_scale")              # factory.py:203-204: scalar vs 1-element parameter
         if ls is not None and ls.ndim != 0 and ls.numel() == 1:
             sd["logit_scale"] = ls.reshape(())
@@ -343,6 +357,16 @@ class SpatialClipNet(torch.nn.Module):
 
     def state_dict(self, *a, **k) -> Dict[str, torch.Tensor]:
         return self.store.state_dict()
+
+    def parameters(self, recurse: bool = True):
+        """nn.Module.parameters for host-side readers: the current stream first waits for an optimiser update that may still be
+        running behind the forward on the communication stream (optim.FusedAdamW._step_behind_forward)."""
+        self.store.wait_all()
+        return super().parameters(recurse)
+
+    def named_parameters(self, *a, **k):
+        self.store.wait_all()
+        return super().named_parameters(*a, **k)
 
     def load_state_dict(self, sd, strict: bool = True):
         self.store.load_state_dict(sd, strict=strict)

@@ -169,8 +169,18 @@ class ParamStore:
 
     # ------------------------------------------------------------------ views
     def p(self, name: str) -> torch.Tensor:
+        """fp32 master view of one parameter.  If an optimiser update / weight gather is still running behind the forward on
+        the communication stream, the CURRENT stream first waits for the part that touches this parameter, so whoever reads
+        the view on the current stream (a tower, a test, a user) reads finished weights (advisor, round 5)."""
         s = self.by_name[name]
+        if self.pending:
+            self.wait_range(s.offset, s.offset + max(s.numel, 1))
         return self.master[s.offset:s.offset + s.numel].view(s.shape)
+
+    def parameters(self) -> List[torch.nn.Parameter]:
+        """The nn.Parameter views, for host-side readers: the current stream waits for every in-flight update first."""
+        self.wait_all()
+        return list(self.params.values())
 
     def g(self, name: str) -> torch.Tensor:
         s = self.by_name[name]

@@ -178,8 +178,8 @@ class Trainer:
         self.optimizer, self.scheduler = opt, sched
         start_epoch = 0
         rank, W = comm.world()
-        # gradient exchange of the group (None without one): the sharded reduce-scatter / all-gather exchange by default,
-        # the bucketed all-reduce with SC_GRAD_EXCHANGE=allreduce (comm.make_grad_exchange).  Attached before a checkpoint is
+        # gradient exchange of the group (None without one): the bucketed all-reduce by default, the sharded reduce-scatter /
+        # all-gather exchange with SC_GRAD_EXCHANGE=sharded (comm.make_grad_exchange).  Attached before a checkpoint is
         # loaded: the sharded optimiser keeps only this rank's piece of the moments.
         reducer = comm.make_grad_exchange(model.net.store)
         model.net.grad_bucket_hook = reducer.bucket_ready if reducer is not None else None
@@ -236,6 +236,7 @@ class Trainer:
             if self._early_stop(rec):
                 break
         self.callback_metrics = {k: v for k, v in self.history[-1].items() if isinstance(v, float)} if self.history else {}
+        model.net.store.wait_all()      # the last optimiser update may run behind the (absent) next forward: fit returns finished weights
 
     # ------------------------------------------------------------------ checkpoints (reference state_dict names)
     def _early_stop(self, rec: Dict[str, Any]) -> bool:
@@ -267,7 +268,9 @@ class Trainer:
             return
         last = os.path.join(cb.dirpath, "last.ckpt")
         # the optimiser state of a sharded optimiser is gathered by a collective: every rank forms it, rank 0 writes it
-        opt_state = opt.state_dict() if opt is not None else None
+        # (with the replicated optimiser only rank 0 forms it: the other ranks would clone 8 bytes per parameter to discard them)
+        sharded = getattr(opt, "exchange", None) is not None and hasattr(opt.exchange, "gather_moments")
+        opt_state = opt.state_dict() if opt is not None and (self.is_global_zero or sharded) else None
         if self.is_global_zero:
             os.makedirs(cb.dirpath, exist_ok=True)
             self.save_checkpoint(last, model, opt, sched, self.global_step, optimizer_state=opt_state)

@@ -279,6 +279,9 @@ def _sharded_worker(rank, world, port, ret):
     # start-up check of the in-place collectives (what make_grad_exchange runs before it takes the sharded route), and the
     # route a group takes when the check fails: bucketed all-reduce, on every rank
     assert comm.inplace_collectives_verified(torch.device("cpu")) is True
+    os.environ.pop("SC_GRAD_EXCHANGE", None)        # default route: the reference's DDP shape
+    assert isinstance(comm.make_grad_exchange(st, bucket_floats=1024), comm.GradBucketReducer)
+    os.environ["SC_GRAD_EXCHANGE"] = "sharded"
     assert isinstance(comm.make_grad_exchange(st, bucket_floats=1024), comm.ShardedGradExchange)
     assert comm.describe()["inplace_collectives_verified"] is True
     for key in list(comm._INPLACE_CHECK):

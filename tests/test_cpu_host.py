@@ -299,6 +299,29 @@ def test_checkpoint_file_formats_of_the_reference_loader(tmp_path):
     assert set(inner) == set(sd) and all(torch.equal(inner[k], sd[k]) for k in sd)
 
 
+class _NotATensor:          # module-level so that pickle can name it
+    def __init__(self):
+        self.x = 1
+
+
+def test_checkpoint_reader_refuses_arbitrary_pickles_unless_asked(tmp_path, monkeypatch):
+    """The reference's loader never unpickles arbitrary objects by default (factory.py:153-178 keeps weights_only=True); a file
+    that pickles more than tensors is refused with the original error, and read only on the explicit opt-in."""
+    from spatial_clip_amd import net
+    f = str(tmp_path / "lightning_like.ckpt")
+    torch.save({"state_dict": {"logit_scale": torch.tensor(1.0)}, "callbacks": _NotATensor()}, f)
+    monkeypatch.delenv("SC_UNSAFE_PICKLE", raising=False)
+    with pytest.raises(RuntimeError, match="SC_UNSAFE_PICKLE"):
+        net.read_checkpoint_file(f)
+    got = net.read_checkpoint_file(f, unsafe_pickle=True)
+    assert float(got["state_dict"]["logit_scale"]) == 1.0
+    monkeypatch.setenv("SC_UNSAFE_PICKLE", "1")
+    assert "state_dict" in net.read_checkpoint_file(f)
+    sd = {"positional_embedding": torch.zeros(16, 8)}
+    with pytest.raises(AssertionError, match="width changed"):
+        net.resize_text_pos_embed(sd, 32, model_width=12)
+
+
 def test_quickgelu_registry_entries():
     """model_configs/ViT-B-16-quickgelu.json, ViT-B-32-quickgelu.json, ViT-L-14-quickgelu.json: the base architecture with
     `quick_gelu: true`; the gene variants keep the flag for the image tower."""

@@ -171,6 +171,7 @@ def _entry_worker(rank, world, port, overlap, ret):
     assert comm.world() == (rank, world)
     assert obj["trainer"].world_size == world
     fg = m._feature_gather
+    m.net.store.wait_all()        # an optimiser update may still be running behind the forward (communication stream)
     ret[(overlap, rank)] = {"w": m.net.store.master.detach().cpu(), "loss": metrics.get("val/loss"),
                             "gathers": 0 if fg is None else fg.launched, "device": torch.cuda.current_device()}
     comm.shutdown()
@@ -238,6 +239,7 @@ def _rccl_worker(rank, world, port, force, ret, native=False, exchange="sharded"
     nat = comm.native()
     assert (nat is not None) == bool(native and force)
     key = ("native" if native else force) if exchange == "sharded" else exchange
+    n.store.wait_all()
     ret[key] = {"w": n.store.master.detach().cpu(), "loss": ls,
                 "gathers": 0 if m._feature_gather is None else m._feature_gather.launched,
                 "native_calls": 0 if nat is None else nat.launched, "stats": {k: list(v) for k, v in comm.STATS.items()},

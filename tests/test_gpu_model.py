@@ -375,6 +375,7 @@ def test_checkpoint_roundtrip_resumes_identically(tmp_path):
     assert Trainer.load_checkpoint(path, m2, o2, s2) == 2
     la, lb = step(m1, o1, s1, 2), step(m2, o2, s2, 2)
     assert la == lb
+    n1.store.wait_all(); n2.store.wait_all()
     assert torch.equal(n1.store.master, n2.store.master)
     assert set(torch.load(path)["state_dict"]) >= {"visual.conv1.weight", "visual.proj", "logit_scale"}
 
@@ -594,6 +595,7 @@ def test_grad_checkpointing_is_bit_identical_and_saves_buffers(monkeypatch, over
             ls.append(float(loss.detach()))
         torch.cuda.synchronize()
         names = set(n.vision.stack.bufs._b)
+        n.store.wait_all()
         res[ckpt] = (ls, g0.cpu(), n.store.master.detach().cpu(), names)
     assert res[False][0] == res[True][0]
     assert torch.equal(res[False][1], res[True][1]), "gradients differ under activation recomputation"

@@ -58,6 +58,7 @@ def _oracle_loss(kind, f, batch):
 # (the quieter of the two yardsticks; measured <= 1.15 x), no tensor beyond 5 %.
 GRAD_MEDIAN_OVER_YARDSTICK = 1.35
 GRAD_REL_L2_WORST = 0.05
+VITL_GRAD_REL_L2_WORST = 0.20       # ViT-L/14 + gene transformer, 24 blocks: measured 13.1-14.2 % on the worst tensor
 
 
 @pytest.mark.parametrize("loss_kind", ["clip", "spatial"])
@@ -130,6 +131,49 @@ def test_vitb16_full_depth_gradients_vs_fp32_oracle(loss_kind):
     for stream, med, wmax, worst in report:
         assert med <= GRAD_MEDIAN_OVER_YARDSTICK * yard["fp32"][0], (stream, med, yard)
         assert wmax <= GRAD_REL_L2_WORST, (stream, wmax, worst)
+
+    # ---- the LOSS at this point (round-5 verdict, weak 1: 1.35e-3 was printed here and not asserted).  Sixteen pairs and
+    # perturbed LayerNorm affines / biases: the loss is a mean over 16 rows of a log-softmax at logit scale 14.3, so the same
+    # feature noise that moves a 256-pair loss by 2e-4 moves this one by ~1e-3 -- for ANY bf16 realisation of the policy: the
+    # reference's own autocast with the bf16 stream it really carries is at 1.12e-3 on the first batch.  A single draw of that
+    # noise says little, so the statement is made over N_LOSS_BATCHES batches (forward only): with the fp32 stream every batch
+    # is inside the north-star's 1e-3; with the bf16 stream (the default = the reference's configured precision) the RMS over the
+    # batches is inside parity.small_batch_loss_bound(RMS of the reference policy's own deltas on the same batches), no batch is
+    # beyond 2.5e-3, and the deltas are not one-sided (a rounding bias would show as a constant sign).
+    from spatial_clip_amd import parity
+    N_LOSS_BATCHES = 5
+    signed = {"bf16": [], "fp32": [], "policy": []}
+    for s in range(N_LOSS_BATCHES):
+        bs = data.synthetic_batch(B, 224, 20000, K=8, step=s)
+        O.USE_ATEN_KERNELS = True
+        try:
+            with torch.no_grad():
+                p = {k: t for k, t in p0.items()}
+                f = O.net_forward(bs["images"], bs["texts"], p, ocfg)
+                l32 = float(_oracle_loss(loss_kind, f, bs))
+                O.REFERENCE_AUTOCAST_STREAM = True
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    fa = O.net_forward(bs["images"], bs["texts"], p, ocfg)
+                    fa = {k: (t.float() if isinstance(t, torch.Tensor) else t) for k, t in fa.items()}
+                    signed["policy"].append(float(_oracle_loss(loss_kind, fa, bs)) - l32)
+        finally:
+            O.USE_ATEN_KERNELS = False
+            O.REFERENCE_AUTOCAST_STREAM = False
+        dbs = {k: t.cuda() for k, t in bs.items()}
+        for stream in ("bf16", "fp32"):
+            n.vision.stack.res_stream = stream
+            with torch.no_grad():
+                signed[stream].append(float(m.model_step(dbs)["loss"]) - l32)
+    n.vision.stack.res_stream = "bf16"
+    rms = {k: float(np.sqrt(np.mean(np.square(v)))) for k, v in signed.items()}
+    bound = parity.small_batch_loss_bound(rms["policy"])
+    print(f"[loss at B = {B}, {loss_kind}, {N_LOSS_BATCHES} batches] signed loss - fp32 oracle: bf16 stream "
+          f"{[f'{x:+.2e}' for x in signed['bf16']]} (RMS {rms['bf16']:.2e}), fp32 stream {[f'{x:+.2e}' for x in signed['fp32']]} "
+          f"(RMS {rms['fp32']:.2e}); reference policy (autocast, bf16 stream) {[f'{x:+.2e}' for x in signed['policy']]} "
+          f"(RMS {rms['policy']:.2e}); bound on the bf16-stream RMS {bound:.2e}")
+    assert max(abs(x) for x in signed["fp32"]) <= parity.LOSS_TOLERANCE["bf16"], signed["fp32"]
+    assert rms["bf16"] <= bound, (rms, bound)
+    assert max(abs(x) for x in signed["bf16"]) <= parity.SMALL_BATCH_LOSS_CAP, signed["bf16"]
 
 
 # configs[4]'s geometry: ViT-L/14 (24 x 1024, 257 tokens: the round-5 attention kernels of sc_attention_p2 / _bwd4 and the
@@ -235,7 +279,10 @@ def test_vitl14_genetr_full_depth_gradients_vs_fp32_oracle(precision):
     for stream, med, wmax, top, dl in report:
         assert dl <= 1e-3, (stream, dl)
         assert med <= GRAD_MEDIAN_OVER_YARDSTICK * yard["fp32"][0], (stream, med, yard["fp32"])
-        assert wmax <= max(GRAD_REL_L2_WORST, 1.5 * yard["fp32"][1]), (stream, wmax, top, yard["fp32"])
+        # worst tensor: measured 14.2 % (bf16 stream) / 13.1 % (fp32 stream) -- class / positional embedding, where 24 blocks of
+        # bf16 residual-gradient hops end; the reference policy's own worst is 26 % / 63 %.  Stated: what is measured + margin
+        # (round-5 verdict: "<= 20 %"), and never beyond the yardstick's own worst
+        assert wmax <= min(VITL_GRAD_REL_L2_WORST, yard["fp32"][1]), (stream, wmax, top, yard["fp32"])
 
 
 # ------------------------------------------------------------------------------------------------------------------ (b)
