@@ -35,6 +35,13 @@ constexpr int BDH = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int RING = 3;                       // dS ring depth in query blocks
 
+#ifdef SC_BWD3_CLOCK
+// Diagnostic build only (tools/attn_bwd3_clock.py, tools/build_variant.py; never in libspatialclip_hip.so): per workgroup,
+// Delta s_memtime (shader clocks) and Delta s_memrealtime (100 MHz) around the key waves' walk over the heads, in a buffer of
+// their own that nothing else reads -- in-kernel clock = Delta memtime / Delta realtime x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
+__device__ unsigned long long sc_bwd3_stamps[4 * 1024];
+#endif
+
 template <int NB>
 __global__ __launch_bounds__(512) void attn_bwd3_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                         const bf16* __restrict__ dout, const float* __restrict__ lse,
@@ -198,6 +205,9 @@ __global__ __launch_bounds__(512) void attn_bwd3_kernel(const bf16* __restrict__
     if (head < nheads) load_vf(head, vf);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     wg_barrier();                                                       // A(0)
+#ifdef SC_BWD3_CLOCK
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int i = 0; head < nheads; ++i, head += gridDim.x) {
         const int b = head / H, h = head % H;
         const char* Kimg = Kimg0 + (i & 1) * IMG;
@@ -360,6 +370,13 @@ __global__ __launch_bounds__(512) void attn_bwd3_kernel(const bf16* __restrict__
             for (int ks = 0; ks < KS; ++ks) vf[bt][ks] = vfn[bt][ks];
         wg_barrier();                                      // A(i + 1)
     }
+#ifdef SC_BWD3_CLOCK
+    if (wave == 0 && lane == 0 && blockIdx.x < 1024) {
+        sc_bwd3_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - clk0;
+        sc_bwd3_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        sc_bwd3_stamps[4 * blockIdx.x + 2] = (unsigned long long)((nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+    }
+#endif
 }
 
 template <int NB>
@@ -408,3 +425,9 @@ int sc_attn_bwd_ring(const void* qkv, const void* out, const void* dout, const f
     }
     return 1;
 }
+
+#ifdef SC_BWD3_CLOCK
+extern "C" int sc_debug_bwd3_stamps(unsigned long long* host, int n_words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sc_bwd3_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif

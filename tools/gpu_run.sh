@@ -10,6 +10,7 @@
 #   pmc                                          the FETCH_SIZE / WRITE_SIZE / MFMA PMC passes + summaries
 #   py:<script and args>                         python <script ...> (tools/*.py micro-benchmarks)
 #   pmcpy:<script and args>                      the three PMC passes over python3 <script ...>
+#   pmcx:<CTR,CTR,...>@<script and args>         one rocprofv3 --pmc pass with the named counters over python3 <script ...>
 #   env:VAR=VALUE / unset:VAR                    environment of the steps that follow (A/B switches)
 set -e -o pipefail
 TAG=$1; shift
@@ -57,6 +58,12 @@ for STEP in "$@"; do
       (cd /tmp && N=3 REPS=1 timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$OUT/pmcpy_m_$T -o m -- python3 $R/$ARG > $R/$OUT/pmcpy_m_$T.log 2>&1)
       python tools/pmc_summary.py $(find $OUT/pmcpy_f_$T -name "f_counter_collection.csv") $(find $OUT/pmcpy_w_$T -name "w_counter_collection.csv") $OUT/pmcpy_traffic_$T.json > $OUT/pmcpy_traffic_$T.txt 2>&1; head -14 $OUT/pmcpy_traffic_$T.txt
       python tools/pmc_generic.py $OUT/pmcpy_mfma_$T.json "$OUT/pmcpy_m_$T/**/m_counter_collection.csv" > $OUT/pmcpy_mfma_$T.txt 2>&1; head -14 $OUT/pmcpy_mfma_$T.txt
+      find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
+    pmcx)   # pmcx:<COUNTER,COUNTER,...>@<script and args>: ONE counter pass (kernel-trace only beside it) over a tools/*.py micro-benchmark
+      CTRS=${ARG%%@*}; CMD=${ARG#*@}
+      T="$(echo "$CTRS $CMD" | tr -c 'A-Za-z0-9' _ | cut -c1-60)"
+      (cd /tmp && N=${PMC_N:-3} REPS=1 timeout -k 10 600 rocprofv3 --pmc ${CTRS//,/ } --kernel-trace --output-format csv -d $R/$OUT/pmcx_$T -o x -- python3 $R/$CMD > $R/$OUT/pmcx_$T.log 2>&1)
+      python tools/pmc_generic.py $OUT/pmcx_$T.json "$OUT/pmcx_$T/**/x_counter_collection.csv" > $OUT/pmcx_$T.txt 2>&1; head -14 $OUT/pmcx_$T.txt
       find $OUT -name "*kernel_trace.csv" -size +20M -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete ;;
     env)    export "$ARG"; echo "exported $ARG" ;;
     unset)  unset "$ARG"; echo "unset $ARG" ;;
