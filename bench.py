@@ -300,6 +300,9 @@ def main():
                     help="activation recomputation (LayerNorm outputs, GELU output): configs[4] at 1024 pairs per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: e4m3 forward GEMMs of the transformer blocks (BASELINE configs[4]); backward stays bf16")
+    ap.add_argument("--graph", default=os.environ.get("SC_GRAPH", "auto"), choices=["auto", "on", "off", "1", "0"],
+                    help="the step as ONE hipGraph (spatial_clip_amd/graph.py): auto = capture it, time replay against enqueueing "
+                         "over a few untimed steps and keep the faster form; single process, bf16 only")
     ap.add_argument("--residual-stream", default="bf16", choices=["fp32", "bf16"],
                     help="the forward residual stream of the patch towers: bf16 like the reference's autocast (default) or fp32")
     args = ap.parse_args()
@@ -372,7 +375,17 @@ def main():
         b = make_batch(cfg, B, args.n_genes, s, rank, world, rates)
         batches.append({k: v.cuda() for k, v in b.items()})
 
-    def step(i):
+    from spatial_clip_amd import graph as sc_graph
+    gmode = {"1": "on", "0": "off"}.get(args.graph, args.graph)
+    gstep = sc_graph.GraphedTrainStep(m, opt, max_norm=1.0, grad_scale=1.0 / world) if (world == 1 and gmode != "off") else None
+    use_graph = [False]
+    graph_info = {"mode": gmode, "used": False, "why": "off" if gstep is None else None}
+
+    def step(i, eager=False):
+        if use_graph[0] and not eager:
+            loss = gstep(batches[i % 2])          # static-buffer copy + 12-byte hyper-parameter copy + ONE graph launch
+            sched.step()
+            return loss
         with streams.chain_stream():       # same stream role as Trainer.fit (high-priority chain, side-stream wgrads)
             return step_(i)
 
@@ -412,6 +425,35 @@ def main():
             step(i)
         torch.cuda.synchronize()
         note(f"weight-gradient side stream per stack: {n.side_stream_choice()}")
+    # The step as one hipGraph (graph.py): captured once the schedule is fixed; `auto` keeps it only where replaying beats
+    # enqueueing -- it does when the host is the bottleneck (small batches, the two-tower text models), not when the GPU is.
+    if gstep is not None:
+        why = gstep.capturable()
+        if why is None:
+            def timed_ms(k, eager):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for i in range(k):
+                    step(setup_steps + i, eager=eager)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / k * 1e3
+            use_graph[0] = True
+            step(0)                               # capture + first replay
+            torch.cuda.synchronize()
+            if gstep.graph is None:
+                use_graph[0] = False
+                graph_info["why"] = f"capture failed: {gstep.failed}"
+            else:
+                ms_g = min(timed_ms(3, False), timed_ms(3, False))
+                ms_e = min(timed_ms(3, True), timed_ms(3, True))
+                graph_info.update(replay_ms=round(ms_g, 3), enqueue_ms=round(ms_e, 3))
+                use_graph[0] = gmode == "on" or ms_g < ms_e * 0.995
+                graph_info["why"] = "replay is faster" if use_graph[0] else "enqueueing is at least as fast (GPU-bound step)"
+                setup_steps += 13
+        else:
+            graph_info["why"] = why
+        graph_info["used"] = use_graph[0]
+        note(f"hipGraph step: {graph_info}")
     note(f"model + {len(batches)} batches resident; warm-up ({args.warmup} steps)")
     for i in range(args.warmup):
         step(i)
@@ -444,12 +486,12 @@ def main():
             if not overlap:                     # ... and nothing else beside a launch either: the optimiser as one launch in front
                 os.environ["SC_ADAMW_BEHIND"] = "0"      # of the forward instead of bucket by bucket behind it (read at every step)
             for i in range(2):
-                step(args.warmup + args.steps + i)
+                step(args.warmup + args.steps + i, eager=True)
             fence()
             ops.KERNEL_EVENTS = []
             t1 = time.perf_counter()
             for i in range(args.steps):
-                step(args.warmup + args.steps + 2 + i)
+                step(args.warmup + args.steps + 2 + i, eager=True)      # event markers per launch: the enqueued form
             fence()
             d = time.perf_counter() - t1
             ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
@@ -557,6 +599,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_steps": setup_steps,
                "side_stream": n.side_stream_choice() if setup_steps else os.environ.get("SC_OVERLAP"),
                "side_stream_trial_ms": n.side_stream_timing() if setup_steps else None,
+               "hip_graph": graph_info, "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"{args.model} image tower + " + (

@@ -374,6 +374,15 @@ int sc_grad_norm(const float* grads, long long n, float grad_scale, float max_no
 int sc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                   const float* norm_clip, void* params_bf16, void* stream);
+/* sc_adamw_step with its step-dependent scalars in DEVICE memory, hyper[3] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)}:
+ * the launch is identical from step to step, so a whole training step (forward, backward, clip, AdamW) can be captured
+ * into ONE hipGraph and replayed while the LambdaLR schedule (src/models/spatial_clip_module.py:146-158) and Adam's bias
+ * correction advance on the host -- the reference's optimizer.step() + scheduler.step() pair, minus ~700 launches of host
+ * work per step on the small-batch configurations (configs/experiment/medium_*.yaml: ViT-B-32, batch 32). */
+int sc_adamw_hyper_host(float lr, float beta1, float beta2, int step, float* out3_host);   /* fills a HOST triple for the copy */
+int sc_adamw_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                      const float* hyper, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                      const float* norm_clip, void* params_bf16, void* stream);
 /* The two halves of sc_grad_norm for an optimiser that owns 1/W of every gradient bucket (reduce-scatter ->
  * AdamW on the rank's shard -> all-gather; Lightning's DDP mean, configs/trainer/ddp.yaml:4, replaced): 1024 fp64 partial
  * sums of squares per contiguous piece of the shard, then -- after the caller has all-reduced (SUM) the concatenated

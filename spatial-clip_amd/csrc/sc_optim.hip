@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v, long long n,
                                                     float lr, float b1, float b2, float eps, float wd, float bc1,
                                                     float bc2_sqrt, float gscale, const float* __restrict__ normclip,
-                                                    bf16* __restrict__ pbf) {
+                                                    bf16* __restrict__ pbf, const float* __restrict__ hyper = nullptr) {
+    if (hyper != nullptr) {     // step-dependent scalars from device memory: a captured hipGraph replays this launch every step
+        lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2];
+    }
     const float gs = gscale * (normclip ? normclip[1] : 1.0f);
     const long long n4 = n >> 2;
     const float decay = 1.0f - lr * wd;
@@ -118,17 +121,47 @@ extern "C" int sc_grad_norm_final(const double* partial, int n_partial, float gr
     return 0;
 }
 
+// host-side: the two bias-correction scalars exactly as sc_adamw_step forms them (one definition for the eager and the
+// graph-replayed update: bit-identical weights)
+static inline void adamw_bias_corrections(float beta1, float beta2, int step, float* bc1, float* bc2s) {
+    *bc1 = 1.0f - powf(beta1, (float)step);
+    *bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+}
+
+extern "C" int sc_adamw_hyper_host(float lr, float beta1, float beta2, int step, float* out3_host) {
+    SC_CHECK(out3_host != nullptr && step >= 1, "sc_adamw_hyper_host: host output triple required, step >= 1");
+    out3_host[0] = lr;
+    adamw_bias_corrections(beta1, beta2, step, out3_host + 1, out3_host + 2);
+    return 0;
+}
+
 extern "C" int sc_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                              const float* norm_clip, void* params_bf16, void* stream) {
     SC_CHECK(n > 0 && (n % 4) == 0 && step >= 1, "sc_adamw_step: n must be a positive multiple of 4, step >= 1");
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    float bc1, bc2s;
+    adamw_bias_corrections(beta1, beta2, step, &bc1, &bc2s);
     long long nb = (n / 4 + 255) / 256;
     if (nb > 4096) nb = 4096;
     adamw_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                                                            weight_decay, bc1, bc2s, grad_scale, norm_clip,
                                                            (bf16*)params_bf16);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same update with its step-dependent scalars read from DEVICE memory: hyper[3] = {lr, 1 - beta1^step,
+// sqrt(1 - beta2^step)} (what sc_adamw_step derives from its host arguments).  A training step captured into a hipGraph
+// (spatial_clip_amd/graph.py) replays identical launches; the host refreshes the three floats before each replay.
+extern "C" int sc_adamw_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                                 const float* hyper, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                 const float* norm_clip, void* params_bf16, void* stream) {
+    SC_CHECK(n > 0 && (n % 4) == 0 && hyper != nullptr, "sc_adamw_step_dev: n must be a positive multiple of 4, hyper required");
+    long long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    adamw_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, 0.f, beta1, beta2, eps,
+                                                           weight_decay, 1.f, 1.f, grad_scale, norm_clip, (bf16*)params_bf16,
+                                                           hyper);
     SC_LAUNCH_CHECK();
     return 0;
 }

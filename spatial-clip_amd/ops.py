@@ -534,6 +534,14 @@ def adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_scale, norm_
                                    _ptr(p_bf16), _stream()), "sc_adamw_step")
 
 
+def adamw_step_dev(p, g, m, v, n, hyper, beta1, beta2, eps, wd, grad_scale, norm_clip, p_bf16=None):
+    """AdamW with {lr, 1 - beta1^step, sqrt(1 - beta2^step)} read from the device tensor ``hyper`` (graph-captured steps)."""
+    _req(hyper, torch.float32, "hyper")
+    check(_lib.lib().sc_adamw_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, hyper.data_ptr(), float(beta1),
+                                       float(beta2), float(eps), float(wd), float(grad_scale), _ptr(norm_clip), _ptr(p_bf16),
+                                       _stream()), "sc_adamw_step_dev")
+
+
 def cast_transpose_batched(master, desc, tile_prefix, n, total_tiles, mirror_bf16=None):
     check(_lib.lib().sc_cast_transpose_batched(master.data_ptr(), _ptr(mirror_bf16), desc.data_ptr(),
                                                tile_prefix.data_ptr(), n, total_tiles, _stream()),

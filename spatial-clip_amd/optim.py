@@ -38,6 +38,9 @@ class FusedAdamW:
         self.step_count = 0
         self.exchange = None        # comm.ShardedGradExchange when this rank owns 1/W of every gradient bucket
         self._behind = None         # bucket plan of the replicated optimiser's overlapped form (_step_behind_forward)
+        # graph-captured steps (graph.GraphedTrainStep): the step-dependent scalars live in device memory
+        self.hyper = None           # fp32 [3] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)}
+        self._hyper_host = None     # pinned staging of the same
 
     def attach_exchange(self, exchange) -> None:
         """Data-parallel runs: hand the optimiser the gradient exchange of the process group.  With a
@@ -135,6 +138,38 @@ class FusedAdamW:
                 done = torch.cuda.Event()
                 done.record(side)
                 st.pending.append((lo, hi, done))
+        return self.norm_clip
+
+    # ---- graph-captured steps: identical launches every step, step-dependent scalars refreshed from the host
+    def refresh_hyper(self) -> None:
+        """Write {lr, 1 - beta1^step, sqrt(1 - beta2^step)} for the step about to run (``step_count`` already advanced) into
+        the device triple ``self.hyper``: one 12-byte async H2D copy on the current stream, enqueued in front of the graph
+        replay that reads it."""
+        g = self.param_groups[0]
+        if self.hyper is None:
+            self.hyper = torch.zeros(3, dtype=torch.float32, device=self.store.device)
+            self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        # formed by the library itself, with the expressions of sc_adamw_step: same bits as the eager launch
+        from . import _lib
+        _lib.check(_lib.lib().sc_adamw_hyper_host(float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), int(self.step_count),
+                                                  self._hyper_host.data_ptr()), "sc_adamw_hyper_host")
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def step_captured(self, grad_scale: float = 1.0, max_norm: Optional[float] = None) -> torch.Tensor:
+        """The replicated one-launch update in the form a hipGraph can replay: clip coefficient and the step-dependent
+        scalars from device memory (``refresh_hyper``), no host-side step counter.  Single process only."""
+        if self.exchange is not None:
+            raise RuntimeError("step_captured: the sharded optimiser issues collectives; graph capture is single-process")
+        g = self.param_groups[0]
+        st = self.store
+        st.wait_all()
+        clip = None
+        if max_norm is not None and max_norm > 0:
+            ops.grad_norm(st.grad, st.total, grad_scale, max_norm, self.norm_clip)
+            clip = self.norm_clip
+        ops.adamw_step_dev(st.master, st.grad, self.exp_avg, self.exp_avg_sq, st.total, self.hyper, g["betas"][0],
+                           g["betas"][1], g["eps"], g["weight_decay"], grad_scale, clip, st.master_bf16)
+        st.refresh_compute_copies(mirror_is_fresh=True)
         return self.norm_clip
 
     def zero_grad(self, set_to_none: bool = False) -> None:

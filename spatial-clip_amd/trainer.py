@@ -21,7 +21,7 @@ from typing import Any, Dict, Optional
 
 import torch
 
-from . import comm, streams
+from . import comm, graph, streams
 
 
 def _to_device(batch: Dict[str, Any], device) -> Dict[str, Any]:
@@ -190,6 +190,13 @@ class Trainer:
                 raise FileNotFoundError(f"ckpt_path {ckpt_path!r} does not exist")
             self.global_step = self.load_checkpoint(ckpt_path, model, opt, sched)
             start_epoch = self.global_step // max(n_train, 1)
+        # single process, bf16, FusedAdamW: the step can run as ONE hipGraph (SC_GRAPH=auto: only where the first eager steps
+        # show the host as the bottleneck -- the reference's ViT-B-32 / batch-32 experiments; =1 always; =0 never)
+        gstep = None
+        if reducer is None and graph.graph_mode() != "0" and hasattr(opt, "step_captured") and torch.cuda.is_available():
+            gstep = graph.GraphedTrainStep(model, opt, max_norm=self.gradient_clip_val, grad_scale=1.0 / W,
+                                           policy="always" if graph.graph_mode() == "1" else "host_bound")
+        self.graphed_step = gstep
         vci = self.val_check_interval
         val_every = 0 if self.fast_dev_run else (int(vci) if isinstance(vci, int) and not isinstance(vci, bool)
                                                  else (max(1, int(n_train * vci)) if vci < 1.0 else 0))
@@ -207,12 +214,15 @@ class Trainer:
                 if i < skip:
                     continue
                 batch = _to_device(batch, model.device)
-                with streams.chain_stream():
-                    loss = model.training_step(batch, i)
-                    loss.backward(model.root_gradient(loss))
-                    if reducer is not None:
-                        reducer.finish()
-                    opt.step(grad_scale=1.0 / W, max_norm=self.gradient_clip_val)
+                if gstep is not None:           # one hipGraph per step where the host is the bottleneck (graph.py); eager otherwise
+                    loss = gstep(batch)
+                else:
+                    with streams.chain_stream():
+                        loss = model.training_step(batch, i)
+                        loss.backward(model.root_gradient(loss))
+                        if reducer is not None:
+                            reducer.finish()
+                        opt.step(grad_scale=1.0 / W, max_norm=self.gradient_clip_val)
                 if sched is not None:
                     sched.step()
                 self.global_step += 1

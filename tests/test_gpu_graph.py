@@ -1,0 +1,106 @@
+"""The training step as one hipGraph (spatial_clip_amd/graph.py): replaying the captured step must give the eager step's
+bits -- same kernels, same values, same order -- while the learning-rate schedule and Adam's bias correction advance through
+the device-side triple, and everything the capture cannot take (other batch shapes, multi-rank, e4m3) stays eager."""
+import functools
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pkg():
+    import spatial_clip_amd  # noqa: F401
+    from spatial_clip_amd import data, graph, losses, model_configs as mc, module, net, optim
+    return data, graph, losses, mc, module, net, optim
+
+
+def _build(cfg, loss_kind, seed=3):
+    data, graph, losses, mc, module, net, optim = _pkg()
+    n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=seed)
+    if loss_kind == "clip":
+        loss_fn = losses.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True)
+    else:
+        loss_fn = losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                     neighbor_alpha_scale=0.5, float32_logits=True)
+    m = module.SpatialClipLitModule(
+        n, loss_fn, functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+        functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=3))
+
+    class T:
+        max_steps, max_epochs, estimated_stepping_batches = 40, None, 40
+    m.trainer = T()
+    oc = m.configure_optimizers()
+    return n, m, oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+
+
+def _batches(cfg, B, n, text):
+    data, *_ = _pkg()
+    out = []
+    for s in range(n):
+        b = data.synthetic_batch(B, cfg.vision.image_size, 200, K=4, step=s)
+        if text:
+            b["texts"] = data.synthetic_captions(B, cfg.text.context_length, cfg.text.vocab_size, seed=s)
+        out.append({k: v.cuda() for k, v in b.items()})
+    return out
+
+
+@pytest.mark.parametrize("second,loss_kind,overlap", [("gene", "spatial", "1"), ("text", "clip", "1"), ("gene", "clip", "0")])
+def test_graph_replay_is_bit_identical_to_the_eager_step(second, loss_kind, overlap, monkeypatch):
+    data, graph, losses, mc, module, net, optim = _pkg()
+    monkeypatch.setenv("SC_OVERLAP", overlap)           # pinned schedule: nothing left to decide before the capture
+    text = second == "text"
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 64, 2, 32),
+                      text=mc.TextCfg(16, 97, 64, 2, 2) if text else None, gene=None if text else mc.GeneCfg(200, 64))
+    B, steps = 24, 6
+    batches = _batches(cfg, B, steps, text)
+    ragged = {k: v[:10].contiguous() for k, v in batches[2].items()}        # another shape in the middle: must run eagerly
+    res = {}
+    for mode in ("eager", "graph"):
+        n, m, opt, sched = _build(cfg, loss_kind)
+        step = graph.GraphedTrainStep(m, opt, max_norm=1.0)
+        ls = []
+        for i in range(steps):
+            b = batches[i]
+            loss = step.eager(b) if mode == "eager" else step(b)
+            sched.step()
+            ls.append(float(loss.detach()))
+            if i == 2:
+                loss = step.eager(ragged) if mode == "eager" else step(ragged)
+                sched.step()
+                ls.append(float(loss.detach()))
+        n.store.wait_all()
+        torch.cuda.synchronize()
+        res[mode] = dict(loss=ls, w=n.store.master.detach().clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(),
+                         metrics=m.train_metrics.compute(), steps=opt.step_count, lr=opt.param_groups[0]["lr"],
+                         replays=step.replays, failed=step.failed)
+    assert res["graph"]["failed"] is None, res["graph"]["failed"]
+    assert res["graph"]["replays"] == steps - 1          # the first call captured and replayed; the ragged batch ran eagerly
+    assert res["eager"]["replays"] == 0
+    assert res["eager"]["loss"] == res["graph"]["loss"], (res["eager"]["loss"], res["graph"]["loss"])
+    assert res["eager"]["steps"] == res["graph"]["steps"] == steps + 1
+    assert res["eager"]["lr"] == res["graph"]["lr"]
+    for k in ("w", "m", "v"):
+        assert torch.equal(res["eager"][k], res["graph"][k]), f"{k}: graph replay differs from the eager step"
+    assert res["eager"]["metrics"] == res["graph"]["metrics"]
+    assert res["eager"]["loss"][-1] < res["eager"]["loss"][0]       # and it trains
+
+
+def test_graph_refuses_what_it_cannot_capture(monkeypatch):
+    data, graph, losses, mc, module, net, optim = _pkg()
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 64, 2, 32), text=None, gene=mc.GeneCfg(200, 64))
+    monkeypatch.delenv("SC_OVERLAP", raising=False)     # auto: the schedule trials use timing events -> not before they are done
+    n, m, opt, sched = _build(cfg, "clip")
+    step = graph.GraphedTrainStep(m, opt, max_norm=1.0)
+    assert "not decided" in step.capturable()
+    b = _batches(cfg, 16, 1, False)[0]
+    from spatial_clip_amd import towers
+    need = sum(towers.TransformerStack.OVERLAP_TRIAL_CALLS[1:]) * 2 + towers.TransformerStack.OVERLAP_TRIAL_CALLS[0] + 1
+    for i in range(need):
+        assert step.graph is None
+        step(b)
+        sched.step()
+    assert step.capturable() is None
+    step(b)
+    assert step.graph is not None and step.failed is None and step.replays == 1
