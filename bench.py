@@ -296,6 +296,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-loss-delta", action="store_true")
+    ap.add_argument("--no-comm-probe", action="store_true",
+                    help="N > 1: skip the extra pass that times the waits on communication (exposed_comm_ms) and every collective")
     ap.add_argument("--grad-checkpointing", action="store_true",
                     help="activation recomputation (LayerNorm outputs, GELU output): configs[4] at 1024 pairs per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
@@ -438,7 +440,8 @@ def main():
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t) / k * 1e3
             use_graph[0] = True
-            step(0)                               # capture + first replay
+            step(0)                               # (a shape is captured after it has run eagerly once through the wrapper)
+            step(1)                               # capture + first replay
             torch.cuda.synchronize()
             if gstep.graph is None:
                 use_graph[0] = False
@@ -449,7 +452,7 @@ def main():
                 graph_info.update(replay_ms=round(ms_g, 3), enqueue_ms=round(ms_e, 3))
                 use_graph[0] = gmode == "on" or ms_g < ms_e * 0.995
                 graph_info["why"] = "replay is faster" if use_graph[0] else "enqueueing is at least as fast (GPU-bound step)"
-                setup_steps += 13
+                setup_steps += 14
         else:
             graph_info["why"] = why
         graph_info["used"] = use_graph[0]
@@ -477,6 +480,22 @@ def main():
     # The weight-gradient GEMMs normally run on a side stream beside the chain, which stretches every kernel that
     # shares the chip with them; the kernel's own duration is taken with the side stream off (SC_OVERLAP=0, read by
     # towers at every backward), and the same measurement with it on is reported next to it.
+    # N > 1: the same K steps once more with the communication probe on (comm.CommProbe): HIP timing events around every point
+    # where the compute stream waits for a collective (-> exposed communication per step) and from the issue of every
+    # collective to its completion (-> a lower bound of its achieved bandwidth).  Outside the timed region: the markers are
+    # launches of their own.  All ranks run it (the collectives are collective); rank 0 reports its own numbers.
+    comm_probe = None
+    if world > 1 and not args.no_comm_probe:
+        comm.PROBE = comm.CommProbe()
+        tp = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + args.steps + i, eager=True)
+        t_host_probe = time.perf_counter() - tp
+        fence()
+        comm_probe = comm.PROBE.summary(args.steps)
+        comm.PROBE = None
+        comm_probe["probe_pass_host_enqueue_ms_per_step"] = round(t_host_probe / args.steps * 1e3, 3)
+        note(f"communication probe: exposed {comm_probe['exposed_comm_ms_per_step']} ms/step; {comm_probe['collectives']}")
     events, dt_inst, events_ov, dt_ov = None, None, None, None
     if not args.no_kernel_events:
         def instrumented(overlap):
@@ -617,7 +636,8 @@ def main():
                           "parallelism": f"dp{world}", "loss": float(loss.detach())},
                "n_gpus_live": dist.get_world_size() if world > 1 else 1,
                "rccl_ranks": comm_info["rccl_ranks"],
-               "comm": {**comm_info, "collectives_per_step_and_rank": coll},
+               "comm": {**comm_info, "collectives_per_step_and_rank": coll,
+                        "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3), **(comm_probe or {})},
                "hbm_peak_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                "loss_delta_vs_oracle": None if delta_init is None else delta_init["loss_delta_vs_oracle"],
                "max_abs_feature_delta": None if delta_init is None else delta_init["max_abs_feature_delta"],

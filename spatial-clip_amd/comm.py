@@ -54,6 +54,83 @@ def reset_stats() -> None:
     STATS.clear()
 
 
+class CommProbe:
+    """bench.py's instrumented pass at N > 1 (round-5 verdict item 6): where the compute stream WAITS for communication, and
+    how long each collective takes from the point it is issued.
+
+    ``stall(kind, device, wait_fn)``: ``wait_fn`` makes the current stream wait for a collective (an event wait, a Work.wait,
+    or a collective that runs on the critical path itself); two timing events on the current stream bracket it -- the time
+    between them is communication the step did NOT hide (exposed communication).
+    ``issued(kind, nbytes, device)`` -> token; ``completed(token, waiter)``: a timing event on the issuing stream in front of
+    the collective and one on the probe's own stream behind ``waiter`` (which makes the probe stream wait for the collective):
+    issue-to-completion time, an upper bound of the collective's duration (it includes any queueing in front of it), hence a
+    LOWER bound of its achieved bandwidth.  Off (``PROBE is None``) in the timed region: the markers cost launches."""
+
+    def __init__(self):
+        self.stalls, self.colls = [], []
+        self._stream = {}
+
+    def stream(self, device):
+        key = torch.device(device).index
+        s = self._stream.get(key)
+        if s is None:
+            s = self._stream[key] = torch.cuda.Stream(device=device)
+        return s
+
+    def summary(self, steps: int) -> dict:
+        torch.cuda.synchronize()
+        ex, co = {}, {}
+        for kind, e0, e1 in self.stalls:
+            ex[kind] = ex.get(kind, 0.0) + e0.elapsed_time(e1)
+        for kind, nbytes, e0, e1 in self.colls:
+            c = co.setdefault(kind, [0, 0.0, 0.0])
+            c[0] += 1
+            c[1] += e0.elapsed_time(e1)
+            c[2] += nbytes
+        return {"exposed_comm_ms_per_step": round(sum(ex.values()) / max(steps, 1), 4),
+                "exposed_by_wait_ms_per_step": {k: round(v / max(steps, 1), 4) for k, v in ex.items()},
+                "collectives": {k: {"launches_per_step": round(c[0] / max(steps, 1), 2), "avg_issue_to_done_ms": round(c[1] / max(c[0], 1), 4),
+                                    "payload_gbytes_per_s_lower_bound": round(c[2] / max(c[1], 1e-9) / 1e6, 2)} for k, c in co.items()}}
+
+
+PROBE: Optional[CommProbe] = None
+
+
+def _stalled(kind: str, device, wait_fn) -> None:
+    """Run ``wait_fn`` (which makes the current stream wait for communication); with the probe on, bracket it with timing
+    events on the current stream."""
+    if PROBE is None or torch.device(device).type != "cuda":
+        wait_fn()
+        return
+    cur = torch.cuda.current_stream(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(cur)
+    wait_fn()
+    e1.record(cur)
+    PROBE.stalls.append((kind, e0, e1))
+
+
+def _issued(kind: str, nbytes: int, device, stream=None):
+    if PROBE is None or torch.device(device).type != "cuda":
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record(stream if stream is not None else torch.cuda.current_stream(device))
+    return (kind, int(nbytes), e0, device)
+
+
+def _completed(token, waiter) -> None:
+    """``waiter()`` is called under the probe's own stream and must make THAT stream wait for the collective."""
+    if token is None or PROBE is None:
+        return
+    kind, nbytes, e0, device = token
+    ps = PROBE.stream(device)
+    with torch.cuda.stream(ps):
+        waiter()
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(ps)
+    PROBE.colls.append((kind, nbytes, e0, e1))
+
+
 def route() -> str:
     """Which code enqueues the data-path collectives: 'native' (the kernel library's own RCCL calls on explicit HIP streams,
     SC_COMM_NATIVE=1) or 'torch.distributed' (ProcessGroupNCCL = RCCL on ROCm, or gloo in the CPU / shared-GPU rehearsals)."""
@@ -379,6 +456,7 @@ class FeatureGather:
         self.stream.wait_event(ready)               # the features are final on the compute stream
         with torch.cuda.stream(self.stream):
             _pack(feat, ids_i, ids_t, send)
+            tok = _issued("all_gather(features|ids)", recv.numel() * 4, self.device, self.stream)
             if _native is not None:
                 _native.all_gather(send, recv, self.stream)     # RCCL's kernel is enqueued on the communication stream itself
             else:
@@ -386,6 +464,7 @@ class FeatureGather:
                 work.wait()                         # nccl: the communication stream waits for RCCL's stream (no host block)
             done = torch.cuda.Event()
             done.record(self.stream)
+        _completed(tok, lambda: torch.cuda.current_stream(self.device).wait_event(done))
         self._done[which] = done
         self.launched += 1
 
@@ -401,7 +480,7 @@ class FeatureGather:
         """-> (all_features [G, D] (row stride D or D+4), all_ids_i, all_ids_t)  (ids only for "text")."""
         done = self._done[which]
         if done is not None:
-            torch.cuda.current_stream(self.device).wait_event(done)
+            _stalled(f"feature all-gather ({which})", self.device, lambda: torch.cuda.current_stream(self.device).wait_event(done))
         _, D, with_ids = self._src[which]
         recv = self._recv[which]
         feats = recv[:, :D]
@@ -422,10 +501,13 @@ def reduce_scatter_sum(full: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(full, op=dist.ReduceOp.SUM)
         return full[rank * B:(rank + 1) * B].clone()
     out = torch.empty((B,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
-    if _native is not None and full.is_cuda and full.dtype == torch.float32:
-        _native.reduce_scatter(full, out, torch.cuda.current_stream(full.device))
-    else:
-        dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM)
+
+    def run():
+        if _native is not None and full.is_cuda and full.dtype == torch.float32:
+            _native.reduce_scatter(full, out, torch.cuda.current_stream(full.device))
+        else:
+            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM)
+    _stalled("reduce_scatter(d features): on the critical path", full.device, run)
     return out
 
 
@@ -474,11 +556,19 @@ class GradBucketReducer:
 
     def _launch(self, lo: int, hi: int) -> None:
         self.launched.append((lo, hi))
-        self.works.append(self._reduce(lo, hi))
+        tok = _issued("all_reduce(gradient bucket)", (hi - lo) * 4, self.flat.device) if self.flat.is_cuda else None
+        w = self._reduce(lo, hi)
+        self.works.append(w)
+        if tok is not None:
+            _completed(tok, (lambda: torch.cuda.current_stream(self.flat.device).wait_event(w)) if isinstance(w, torch.cuda.Event)
+                       else (lambda: w.wait()))
 
     def finish(self) -> None:
         if not is_dist():
             return
+        _stalled("gradient all-reduce (finish)", self.flat.device, self._finish)
+
+    def _finish(self) -> None:
         if self.pending is not None:
             self._launch(*self.pending)
             self.pending = None
@@ -615,6 +705,9 @@ class ShardedGradExchange:
         """Flush what backward did not announce and make the current stream wait for every reduce-scatter."""
         if not is_dist():
             return
+        _stalled("gradient reduce-scatter (finish)", self.flat.device, self._finish)
+
+    def _finish(self) -> None:
         self._launch_covered(force=True)
         for w in self._works:
             if isinstance(w, torch.cuda.Event):

@@ -60,6 +60,7 @@ class GraphedTrainStep:
         self._host_ms, self._dev_ms = [], []
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.sig = None
+        self._warm_sig = None
         self.static: Dict[str, torch.Tensor] = {}
         self.extra: Dict[str, Any] = {}
         self.loss: Optional[torch.Tensor] = None
@@ -96,6 +97,8 @@ class GraphedTrainStep:
             loss = self.m.training_step(batch, 0)
             loss.backward(self.m.root_gradient(loss))
             self.opt.step(grad_scale=self.grad_scale, max_norm=self.max_norm)
+        if self.graph is None:
+            self._warm_sig = _signature(batch)      # this shape has now run eagerly (see __call__)
         if probe:
             e1.record()
             self._samples.append(((time.perf_counter() - t0) * 1e3, e0, e1))
@@ -151,6 +154,11 @@ class GraphedTrainStep:
                 return self.eager(batch)
             if not worth:
                 self.failed = "not captured: the eager step is GPU-bound (host enqueue below %.0f %% of the device time)" % (100 * self.HOST_BOUND_RATIO)
+                return self.eager(batch)
+            if _signature(batch) != self._warm_sig:
+                # a shape is captured only right after it has run eagerly: everything a first step creates lazily (activation
+                # buffers, workspaces, the R@k counters and their zero fill, side streams) exists before the capture -- an
+                # allocation + initialisation recorded INTO the graph would be repeated by every replay
                 return self.eager(batch)
             try:
                 self._capture(batch)

@@ -192,15 +192,15 @@ class ParamStore:
         the single-process and all-reduce paths never have anything)."""
         if not self.pending:
             return
-        keep = []
-        cur = None
+        keep, hit = [], []
         for plo, phi, ev in self.pending:
-            if plo < hi and lo < phi:
-                cur = cur or torch.cuda.current_stream(self.device)
-                cur.wait_event(ev)
-            else:
-                keep.append((plo, phi, ev))
+            (hit if (plo < hi and lo < phi) else keep).append((plo, phi, ev))
         self.pending = keep
+        if hit:
+            from . import comm          # (bench.py's instrumented pass times this wait: comm.CommProbe)
+            cur = torch.cuda.current_stream(self.device)
+            comm._stalled("weight refresh behind the forward (optimiser / all-gather)", self.device,
+                          lambda: [cur.wait_event(ev) for _, _, ev in hit])
 
     def wait_names(self, names: List[str]) -> None:
         if self.pending:

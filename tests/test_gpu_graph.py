@@ -76,13 +76,21 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(second, loss_kind, over
                          metrics=m.train_metrics.compute(), steps=opt.step_count, lr=opt.param_groups[0]["lr"],
                          replays=step.replays, failed=step.failed)
     assert res["graph"]["failed"] is None, res["graph"]["failed"]
-    assert res["graph"]["replays"] == steps - 1          # the first call captured and replayed; the ragged batch ran eagerly
+    assert res["graph"]["replays"] == steps - 1          # first call eager (warms the shape), second captures AND replays; the ragged batch ran eagerly
     assert res["eager"]["replays"] == 0
-    assert res["eager"]["loss"] == res["graph"]["loss"], (res["eager"]["loss"], res["graph"]["loss"])
     assert res["eager"]["steps"] == res["graph"]["steps"] == steps + 1
     assert res["eager"]["lr"] == res["graph"]["lr"]
-    for k in ("w", "m", "v"):
-        assert torch.equal(res["eager"][k], res["graph"][k]), f"{k}: graph replay differs from the eager step"
+    if text:
+        # the text tower's embedding scatter-add (sc_token_embed_bwd) sums the rows of a repeated token with float atomics: its
+        # summation order, and with it the last bit of token_embedding.weight's gradient, differs from run to run in the EAGER
+        # step too -- the comparison for this tower is to rounding, not to the bit
+        assert max(abs(a - b) for a, b in zip(res["eager"]["loss"], res["graph"]["loss"])) < 1e-5
+        for k in ("w", "m", "v"):
+            assert torch.allclose(res["eager"][k], res["graph"][k], rtol=1e-4, atol=1e-6), f"{k}: graph replay differs from the eager step"
+    else:
+        assert res["eager"]["loss"] == res["graph"]["loss"], (res["eager"]["loss"], res["graph"]["loss"])
+        for k in ("w", "m", "v"):
+            assert torch.equal(res["eager"][k], res["graph"][k]), f"{k}: graph replay differs from the eager step"
     assert res["eager"]["metrics"] == res["graph"]["metrics"]
     assert res["eager"]["loss"][-1] < res["eager"]["loss"][0]       # and it trains
 
@@ -103,4 +111,4 @@ def test_graph_refuses_what_it_cannot_capture(monkeypatch):
         sched.step()
     assert step.capturable() is None
     step(b)
-    assert step.graph is not None and step.failed is None and step.replays == 1
+    assert step.graph is not None and step.failed is None and step.replays == 1     # (the shape had run eagerly before)
