@@ -275,6 +275,10 @@ int sc_gemm256_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs,
     if (mode == SC_GEMM_TN && ((g.M % 8) != 0 || (g.N % 8) != 0)) return 0;
     const long long work = (long long)g.M * g.N;
     if (work < 256LL * 256 * 8) return 0;
+    if (mode == SC_GEMM_NT && splitk_req <= 1) {      // few tiles: the 128x128 general kernel (see sc_gemm8p_try)
+        static const int small_tiles = getenv("SC_GEMM_SMALL_TILES") ? atoi(getenv("SC_GEMM_SMALL_TILES")) : 100;
+        if (work < 256LL * 256 * small_tiles) return 0;
+    }
     g.ntm = (g.M + BM - 1) / BM;
     g.ntn = (g.N + BN - 1) / BN;
     const int ktiles = g.K / BK;

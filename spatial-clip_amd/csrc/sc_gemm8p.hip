@@ -1393,6 +1393,14 @@ int sc_gemm8p_try(int mode, int epi, GemmArgs& g, int splitk_req, float* slabs, 
     if (g.M < 256 || g.N < 192 || (g.K % BK) != 0) return 0;
     if (mode == SC_GEMM_TN && (epi != SC_EPI_F32 || (g.M % 8) != 0 || (g.N % 8) != 0)) return 0;
     if ((long long)g.M * g.N < 256LL * 256 * 8) return 0;
+    // NT launches with fewer 256x256 tiles than ~0.4 of the chip's CUs go to the 128x128 general kernel: four times the
+    // workgroups, two of them per CU.  Measured (tools/bench_small_m.py, profiles/r06_small_m_kernel_choice.txt; the token
+    // counts of ViT-B-32 + CLIP text tower at the reference's batch 32): 20-84 tiles 1.08-1.52x faster on the small kernel,
+    // 150 tiles and more 1.1-1.5x faster here.  SC_GEMM_SMALL_TILES=<n> moves the threshold (0: never).
+    if (mode == SC_GEMM_NT && splitk_req <= 1) {
+        static const int small_tiles = getenv("SC_GEMM_SMALL_TILES") ? atoi(getenv("SC_GEMM_SMALL_TILES")) : 100;
+        if ((long long)g.M * g.N < 256LL * 256 * small_tiles) return 0;
+    }
     g.ntm = (g.M + BM - 1) / BM;
     g.ntn = (g.N + BN - 1) / BN;
     const int ktiles = g.K / BK;
