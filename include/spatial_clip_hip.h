@@ -252,6 +252,12 @@ int sc_token_embed_fwd(const long long* tokens, const float* table, const float*
                        int V, void* stream);
 int sc_token_embed_bwd(const long long* tokens, const float* dres, float* dtable, float* dpos, int B, int L, int d,
                        int V, void* stream);
+/* The same gradients, bit-reproducible (round 6; the default of the text tower): table row t is summed by ONE wave per
+ * 256-column slab that walks the token list in order -- no float atomics, so repeated tokens (<start_of_text> in every caption)
+ * are added in increasing position.  eot[B] (int32, nullable) = pooled position per caption: positions behind it carry an exactly
+ * zero gradient in the causal tower and are skipped. */
+int sc_token_embed_bwd_det(const long long* tokens, const int* eot, const float* dres, float* dtable, float* dpos, int B, int L,
+                           int d, int V, void* stream);
 int sc_argmax_rows_i64(const long long* tokens, int* out_idx, int B, int L, void* stream);
 int sc_gather_rows_f32(const float* src, const int* idx, int L, float* dst, int B, int d, void* stream);
 int sc_scatter_rows_f32(const float* src, const int* idx, int L, float* dst, void* dst_bf16, int B, int d,

@@ -394,6 +394,67 @@ __global__ void token_embed_bwd_kernel(const long long* __restrict__ tokens, con
     }
 }
 
+// Deterministic form of the scatter-add (round 6).  The atomic kernel above sums the rows of a repeated token (<start_of_text>
+// occurs in every caption) in whatever order the hardware serialises the float atomics: the last bit of dtable differs from run
+// to run, and with it every weight after the first optimiser step.  Here table row t belongs to token class c = t % NC, and ONE
+// wave per (class, 256-column slab) walks the token list IN ORDER: 64 positions per look-up (ballot), the rows of its class's
+// tokens added in increasing position -- consecutive occurrences of one token in a register accumulator, a read-modify-write
+// of the table row only when the token changes -- so every element of dtable is formed by one lane in one fixed order.
+// Positions behind the pooled one (l > eot[b]: causal tower, pooled at the EOT token) carry an exactly zero gradient and are
+// skipped.  Up to four gradient rows are in flight per wave.
+constexpr int TE_NC = 1024;
+__global__ __launch_bounds__(64) void token_embed_bwd_det_kernel(const long long* __restrict__ tokens, const int* __restrict__ eot,
+                                                                 const float* __restrict__ dres, float* __restrict__ dtable,
+                                                                 int rows, int L, int d, int V, int nslab) {
+    const int lane = threadIdx.x;
+    const int cls = blockIdx.x / nslab, slab = blockIdx.x - cls * nslab;
+    const int col = slab * 256 + lane * 4;
+    const bool active = col < d;
+    int cur = -1;                                   // token whose partial sum sits in acc
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto flush = [&]() {
+        if (cur >= 0 && active) {
+            float* w = dtable + (long long)cur * d + col;
+            st4(w, ld4(w) + acc);
+        }
+    };
+    for (int base = 0; base < rows; base += 64) {
+        const int p = base + lane;
+        int tk = -1;
+        if (p < rows) {
+            long long t = tokens[p];
+            t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+            const int b = p / L, l = p - b * L;
+            if ((int)(t % TE_NC) == cls && (eot == nullptr || l <= eot[b])) tk = (int)t;
+        }
+        unsigned long long mask = __ballot(tk >= 0);
+        while (mask) {
+            int bit[4], tok[4];
+            f32x4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {           // up to four matches: their gradient rows requested together
+                bit[u] = mask ? __builtin_ctzll(mask) : -1;
+                if (mask) mask &= mask - 1;
+                tok[u] = bit[u] >= 0 ? __shfl(tk, bit[u], 64) : -1;
+                g[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (bit[u] >= 0 && active) g[u] = ld4(dres + (long long)(base + bit[u]) * d + col);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (bit[u] < 0) break;
+                if (tok[u] != cur) {
+                    flush();
+                    cur = tok[u];
+                    acc = g[u];
+                } else {
+                    acc += g[u];
+                }
+            }
+        }
+    }
+    flush();
+}
+
 __global__ void argmax_rows_kernel(const long long* __restrict__ tokens, int* __restrict__ out, int B, int L) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -453,6 +514,20 @@ extern "C" int sc_token_embed_bwd(const long long* tokens, const float* dres, fl
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     token_embed_bwd_kernel<<<blocks, 256, 0, st>>>(tokens, dres, dtable, B * L, d, V);
+    SC_LAUNCH_CHECK();
+    const long long n4 = (long long)L * d / 4;
+    batch_sum_kernel<<<(int)((n4 + 255) / 256), 256, 0, st>>>(dres, dpos, B, n4);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sc_token_embed_bwd_det(const long long* tokens, const int* eot, const float* dres, float* dtable, float* dpos,
+                                      int B, int L, int d, int V, void* stream) {
+    SC_CHECK(B > 0 && L > 0 && d > 0 && (d % 4) == 0 && V > 0, "sc_token_embed_bwd_det: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(dtable, 0, (size_t)V * d * sizeof(float), st);
+    const int nslab = (d + 255) / 256;
+    token_embed_bwd_det_kernel<<<TE_NC * nslab, 64, 0, st>>>(tokens, eot, dres, dtable, B * L, L, d, V, nslab);
     SC_LAUNCH_CHECK();
     const long long n4 = (long long)L * d / 4;
     batch_sum_kernel<<<(int)((n4 + 255) / 256), 256, 0, st>>>(dres, dpos, B, n4);

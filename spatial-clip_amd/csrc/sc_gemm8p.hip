@@ -851,6 +851,15 @@ int launch_tn(const GemmArgs& g, int nblocks, hipStream_t st) {
 //   row blocks a 32-lane half reads land on eight different 16-byte bank windows; the per-lane swizzle term does not depend on
 //   which of the four reads it is, so they are immediate offsets off one address.
 //   C = a_scale_inv * b_scale_inv * sum (fp32 slabs as above); the fused bias gradient sums the e4m3 A fragments (x a_scale_inv).
+// Block scales of the f8f6f4 MFMA.  Unit scales two ways: E8M0 127 (= 2^0) in the scale registers of the SCALED opcode
+// (v_mfma_scale_..., a 16-byte encoding that loads the scales in front of every MFMA), or the constant 0, for which the compiler
+// selects the UNSCALED opcode v_mfma_f32_16x16x128_f8f6f4 (8-byte encoding, no scale load; the scales are implicitly one).
+// -DSC_F8_SCALED_OPCODE keeps the first form (A/B; tests/test_gpu_fp8.py's exact-integer tests pin the arithmetic of either).
+#ifdef SC_F8_SCALED_OPCODE
+#define SC_F8_UNIT_SCALE 0x7F7F7F7F
+#else
+#define SC_F8_UNIT_SCALE 0
+#endif
 typedef __attribute__((ext_vector_type(8))) int i32x8t;
 struct FragT8 {
     union {
@@ -946,7 +955,7 @@ SC_DEVICE void phase_t8(char* smem, unsigned lds0, const StagerT8& S, int t, con
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
             acc[mi * 4 + ii][nj * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-                t8_cat(nj ? b1[jj] : b0[jj]), af, acc[mi * 4 + ii][nj * 2 + jj], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                t8_cat(nj ? b1[jj] : b0[jj]), af, acc[mi * 4 + ii][nj * 2 + jj], 0, 0, 0, SC_F8_UNIT_SCALE, 0, SC_F8_UNIT_SCALE);
         if ((PH == 1 || PH == 3) && do_cs && ii == wc) cs[mi] += t8_sum(a[ii]);     // fused bias gradient, as in the bf16 kernel
     }
     __builtin_amdgcn_s_setprio(0);
@@ -1142,7 +1151,7 @@ SC_DEVICE void phase_f8(char* smem, const Stager& S, int t, const int (&a_off)[2
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
             acc[mi * 4 + ii][nj * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-                nj ? b1[jj].v : b0[jj].v, a[ii].v, acc[mi * 4 + ii][nj * 2 + jj], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                nj ? b1[jj].v : b0[jj].v, a[ii].v, acc[mi * 4 + ii][nj * 2 + jj], 0, 0, 0, SC_F8_UNIT_SCALE, 0, SC_F8_UNIT_SCALE);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();

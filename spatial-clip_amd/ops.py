@@ -556,7 +556,16 @@ def token_embed_fwd(tokens, table, pos, x, B, L, d, V):
     return x
 
 
-def token_embed_bwd(tokens, dres, dtable, dpos, B, L, d, V):
+def token_embed_bwd(tokens, dres, dtable, dpos, B, L, d, V, eot=None, deterministic=True):
+    """Gradient of the embedding gather + positional embedding.  ``deterministic`` (default): every table row summed in
+    position order by one wave per column slab (bit-reproducible); ``eot`` int32 [B] = pooled positions (rows behind them are
+    skipped: exactly zero in the causal tower).  ``deterministic=False``: float atomics (order-dependent last bit)."""
+    if deterministic:
+        if eot is not None:
+            _req(eot, torch.int32, "eot")
+        check(_lib.lib().sc_token_embed_bwd_det(tokens.data_ptr(), _ptr(eot), dres.data_ptr(), dtable.data_ptr(), dpos.data_ptr(),
+                                                B, L, d, V, _stream()), "sc_token_embed_bwd_det")
+        return
     check(_lib.lib().sc_token_embed_bwd(tokens.data_ptr(), dres.data_ptr(), dtable.data_ptr(), dpos.data_ptr(), B, L, d,
                                         V, _stream()), "sc_token_embed_bwd")
 

@@ -1010,6 +1010,8 @@ class TextTower:
             on_bucket(self.param_names_head())
         cb = (lambda i: on_bucket(self.stack.layer_param_names(i))) if on_bucket is not None else None
         self.stack.backward(dres, dres_bf, last_bias_colsum_done=True, on_layer_done=cb)
-        ops.token_embed_bwd(self.text, dres, s.g("token_embedding.weight"), s.g("positional_embedding"), B, L, d, self.V)
+        # scatter-add of the embedding gather: bit-reproducible by default (SC_EMBED_BWD_ATOMIC=1: the float-atomic kernel, A/B)
+        ops.token_embed_bwd(self.text, dres, s.g("token_embedding.weight"), s.g("positional_embedding"), B, L, d, self.V,
+                            eot=bf.get("eot", (B,), torch.int32), deterministic=os.environ.get("SC_EMBED_BWD_ATOMIC", "0") != "1")
         if on_bucket is not None:
             on_bucket(self.param_names_stem())

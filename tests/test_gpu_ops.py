@@ -584,3 +584,41 @@ def test_cast_transpose_batched_from_master_and_from_mirror():
             assert torch.equal(o[:, :r].cpu(), want.cpu()), (use_mirror, r, c)
             assert bool((o[:, r:] == 5.0).all())
             off += r * c
+
+
+@pytest.mark.parametrize("B,L,d,V", [(64, 77, 512, 49408), (5, 16, 64, 97), (256, 77, 512, 49408)])
+def test_token_embedding_backward_is_deterministic_and_matches_index_add(B, L, d, V):
+    """sc_token_embed_bwd_det (round 6): the scatter-add of the embedding gather without float atomics -- equal to an fp64
+    index_add within fp32 rounding, equal to the atomic kernel within rounding, BIT-identical from launch to launch, rows of
+    absent tokens exactly zero, positions behind the pooled one skipped (they carry zeros in the causal tower)."""
+    ops = _ops()
+    from spatial_clip_amd import data
+    tokens = data.synthetic_captions(B, L, V, seed=3).cuda()
+    eot = torch.empty(B, dtype=torch.int32, device="cuda")
+    ops.argmax_rows(tokens, eot, B, L)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    dres = torch.randn(B * L, d, device="cuda", generator=g)
+    live = (torch.arange(L, device="cuda").view(1, L) <= eot.view(B, 1).long()).view(B * L, 1)
+    dres = dres * live                                   # what the causal tower hands over: zero rows behind the pooled position
+    ref = torch.zeros(V, d, dtype=torch.float64, device="cuda")
+    ref.index_add_(0, tokens.view(-1), dres.double())
+    outs = []
+    for rep in range(3):
+        dt = torch.full((V, d), 7.0, device="cuda")
+        dp = torch.empty(L, d, device="cuda")
+        ops.token_embed_bwd(tokens, dres, dt, dp, B, L, d, V, eot=eot, deterministic=True)
+        outs.append(dt)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    scale = float(ref.abs().max())
+    assert float((outs[0].double() - ref).abs().max()) <= 2e-6 * max(scale, 1.0) * 16          # <= 256 fp32 additions per element
+    used = torch.zeros(V, dtype=torch.bool, device="cuda")
+    used[tokens.view(-1)] = True
+    assert float(outs[0][~used].abs().max()) == 0.0
+    torch.testing.assert_close(dp, dres.view(B, L, d).sum(0), rtol=1e-5, atol=1e-5)
+    da = torch.empty(V, d, device="cuda")
+    ops.token_embed_bwd(tokens, dres, da, dp, B, L, d, V, deterministic=False)
+    torch.testing.assert_close(da, outs[0], rtol=1e-5, atol=1e-5)
+    # without the pooled positions every row is visited: same result (the skipped rows were zeros)
+    dn = torch.empty(V, d, device="cuda")
+    ops.token_embed_bwd(tokens, dres, dn, dp, B, L, d, V, eot=None, deterministic=True)
+    assert torch.equal(dn, outs[0])
