@@ -148,8 +148,12 @@ def describe() -> dict:
         info["world_size"] = dist.get_world_size()
         if info["backend"] == "nccl":
             # a SUM all-reduce of ones over the communicator the step uses: the number of ranks RCCL itself reaches
-            t = torch.ones(1, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            # (SC_COMM_NATIVE=1: through the library's own communicator -- THAT is the one the step's collectives use)
+            t = torch.ones(4, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+            if _native is not None:
+                _native.all_reduce(t, torch.cuda.current_stream(t.device))
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
             info["rccl_ranks"] = int(round(float(t.cpu()[0])))
             try:
                 info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
