@@ -209,7 +209,7 @@ def loss_delta_vs_oracle(m, n, cfg, batch_cpu, loss_kind: str, dtype: str = "bf1
     return res
 
 
-PMC_TRAFFIC_FILES = ("r05_pmc_traffic_summary.json", "r04_pmc_traffic_summary.json")
+PMC_TRAFFIC_FILES = ("r06_pmc_traffic_summary.json", "r05_pmc_traffic_summary.json", "r04_pmc_traffic_summary.json")
 
 
 def pmc_traffic_nt():
@@ -578,7 +578,7 @@ def main():
             roofline["forward_fp8"] = {"achieved": round(f8 / s8 / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
                                        "frac": round(f8 / s8 / 1e12 / 5000.0, 4), "launches_per_step": c8 // args.steps,
                                        "share_of_step_time": round(s8 / dt_inst, 3),
-                                       "note": "v_mfma_scale_f32_16x16x128_f8f6f4 forward GEMMs (e4m3, dense fp8 peak ~5 PFLOP/s)"}
+                                       "note": "e4m3 NT GEMMs on v_mfma_f32_16x16x128_f8f6f4 (dense fp8 peak ~5 PFLOP/s)"}
         if "gemm_tn" in agg:
             fl2, sec2, cnt2 = agg["gemm_tn"][:3]
             roofline["wgrad_tn"] = {"achieved": round(fl2 / sec2 / 1e12, 1), "share_of_step_time": round(sec2 / dt_inst, 3),

@@ -29,7 +29,9 @@ for STEP in "$@"; do
       LOG="$OUT/tests_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-60).log"
       if [ -n "$KEXPR" ]; then timeout -k 10 1100 python -m pytest $FILES -k "$KEXPR" -m gpu -x -q -s 2>&1 | tee "$LOG" | tail -40
       else timeout -k 10 1100 python -m pytest $FILES -m gpu -x -q -s 2>&1 | tee "$LOG" | tail -40; fi ;;
-    bench)  timeout -k 10 900 python bench.py --steps 20 --warmup 5 $ARG > "$OUT/bench_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40).json" 2> "$OUT/bench_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40).err" ; tail -c 600 "$OUT"/bench_*.json | tail -5 ;;
+    bench)  # (file name = first 40 characters of the arguments + a checksum of all of them: two long argument lists that share a prefix must not overwrite each other)
+      BN="bench_$(echo "$ARG" | tr -c 'A-Za-z0-9' _ | cut -c1-40)_$(echo "$ARG" | cksum | cut -d' ' -f1)"
+      timeout -k 10 900 python bench.py --steps 20 --warmup 5 $ARG > "$OUT/$BN.json" 2> "$OUT/$BN.err" ; tail -c 400 "$OUT/$BN.json" ;;
     benchq) timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loss-delta --no-kernel-events $ARG 2> "$OUT/benchq.err" | tee -a "$OUT/benchq.jsonl" | cut -c1-400 ;;
     prof)
       MODE=${ARG%% *}; MODE=${MODE:-single}; EXTRA=""; [[ "$ARG" == *" "* ]] && EXTRA=${ARG#* }      # prof:single+--model+X ...: extra bench.py arguments
