@@ -754,7 +754,7 @@ class ShardedGradExchange:
             st.refresh_range(lo, hi, self._copies[k], self._plans[k], fresh=(a, b))
             done = torch.cuda.Event()
             done.record(self.stream)
-        st.pending.append((lo, hi, done))
+        st.add_pending(lo, hi, done)
 
     def gather_moments(self, shard: torch.Tensor) -> torch.Tensor:
         """A full flat-layout copy of a sharded optimiser-state buffer (checkpoints): collective, every rank calls it."""

@@ -80,6 +80,8 @@ class GraphedTrainStep:
             return "sharded optimiser"
         if os.environ.get("SC_OVERLAP", "auto") not in ("0", "1"):
             for name, stack in net._stacks():
+                if getattr(stack, "no_side_stream", False):       # runs beside the other tower on its own stream: nothing to decide
+                    continue
                 st = getattr(stack, "_ov_auto", None)
                 if not st or any(s["choice"] is None for s in st.values()):
                     return f"side-stream schedule of the {name} stack not decided yet"

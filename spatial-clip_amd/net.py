@@ -18,7 +18,7 @@ from typing import Any, Callable, Dict, List, Optional
 
 import torch
 
-from . import ops
+from . import ops, streams
 from .model_configs import ModelCfg, get_model_config
 from .params import ParamStore
 from .towers import GeneTower, GeneTransformerTower, TextTower, VisionTower
@@ -42,12 +42,24 @@ class _NetFn(torch.autograd.Function):
         # second tower first: its features (and the tile ids) start travelling on the communication stream while the
         # vision tower -- >99 % of the step's FLOPs -- is still running (comm.FeatureGather)
         fg = net.feature_gather
-        txt = net.second.forward(texts)
-        if fg is not None:
-            fg.put("text", txt)
-        img = net.vision.forward(images)
-        if fg is not None:
-            fg.put("image", img)
+        side_by_side = net._towers_side_by_side()
+        if side_by_side:
+            # single process, second tower a transformer: the towers are independent until the loss -- the second one runs on
+            # its own stream beside the vision tower (round 6; fork / join by events, also inside a captured graph)
+            cur = torch.cuda.current_stream(net.device_)
+            ts = streams.tower_stream(net.device_)
+            ts.wait_stream(cur)
+            with torch.cuda.stream(ts):
+                txt = net.second.forward(texts)
+            img = net.vision.forward(images)
+            cur.wait_stream(ts)
+        else:
+            txt = net.second.forward(texts)
+            if fg is not None:
+                fg.put("text", txt)
+            img = net.vision.forward(images)
+            if fg is not None:
+                fg.put("image", img)
         s = torch.empty(1, dtype=torch.float32, device=img.device)
         net.store.wait_names(["logit_scale"])
         ops.exp_scalar(net.store.p("logit_scale").view(1), s)
@@ -254,6 +266,21 @@ class SpatialClipNet(torch.nn.Module):
             if stack is not None:
                 stack.set_grad_checkpointing(enable)
 
+    def _towers_side_by_side(self) -> bool:
+        """Run the second tower on its own stream beside the vision tower?  ``SC_TOWER_OVERLAP`` = auto (default) | 1 | 0, read per
+        call.  auto: single process (with a process group the second tower goes FIRST so that its feature all-gather travels under
+        the vision tower) and a transformer second tower (the gene-MLP is three launches).  Its stack then keeps its weight
+        gradients on its own stream -- a weight-gradient side stream per tower would be the fifth busy stream of the device (§ stream
+        roles: the hardware queues are few).  Same kernels on the same values: bit-identical to the sequential order."""
+        mode = os.environ.get("SC_TOWER_OVERLAP", "auto")
+        if mode == "0" or self.feature_gather is not None or self.grad_bucket_hook is not None:
+            return False
+        stack = getattr(self.second, "stack", None)
+        on = stack is not None and (mode == "1" or mode == "auto")
+        if stack is not None:
+            stack.no_side_stream = on
+        return on
+
     def _stacks(self):
         return [(name, t.stack) for name, t in (("vision", self.vision), ("second", self.second)) if getattr(t, "stack", None) is not None]
 
@@ -403,5 +430,14 @@ class SpatialClipNet(torch.nn.Module):
             d_txt = torch.zeros((B, D), dtype=torch.float32, device=dev)
         if d_img is None:
             d_img = torch.zeros((B, D), dtype=torch.float32, device=dev)
+        if self._towers_side_by_side():
+            cur = torch.cuda.current_stream(dev)
+            ts = streams.tower_stream(dev)
+            ts.wait_stream(cur)                     # d_txt and the forward's activations are final on the chain
+            with torch.cuda.stream(ts):
+                self.second.backward(d_txt, on_bucket=self._bucket)
+            self.vision.backward(d_img, on_bucket=self._bucket)
+            cur.wait_stream(ts)
+            return
         self.second.backward(d_txt, on_bucket=self._bucket)
         self.vision.backward(d_img, on_bucket=self._bucket)

@@ -44,7 +44,9 @@ _slab_cache = {}
 
 
 def _slabs(nfloat: int, device) -> torch.Tensor:
-    key = (device.index,)
+    # scratch is per STREAM: two streams of one step (the towers side by side, net.py; the weight-gradient side stream) must
+    # never share a split-K slab buffer -- launches of one stream are ordered, launches of two are not
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _slab_cache.get(key)
     if buf is None or buf.numel() < nfloat:
         buf = torch.empty(max(nfloat, 1 << 22), dtype=torch.float32, device=device)
@@ -157,7 +159,9 @@ _ws_cache = {}
 
 
 def workspace(nfloat: int, device, tag: str = "ws", dtype=torch.float32) -> torch.Tensor:
-    key = (device.index, tag, dtype)
+    """Scratch of at least ``nfloat`` elements for the launch being enqueued: one buffer per (device, purpose, dtype, STREAM) --
+    see ``_slabs``."""
+    key = (device.index, tag, dtype, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloat:
         buf = torch.empty(max(int(nfloat), 1024), dtype=dtype, device=device)

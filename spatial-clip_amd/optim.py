@@ -137,7 +137,7 @@ class FusedAdamW:
                 st.refresh_range(lo, hi, copies[k], plans[k], fresh=(lo, hi))
                 done = torch.cuda.Event()
                 done.record(side)
-                st.pending.append((lo, hi, done))
+                st.add_pending(lo, hi, done)
         return self.norm_clip
 
     # ---- graph-captured steps: identical launches every step, step-dependent scalars refreshed from the host

@@ -151,7 +151,7 @@ class ParamStore:
         self.total = _round_up(last.offset + _round_up(max(last.numel, 1), ALIGN), ALIGN * self.shard_world)
         # weight refreshes still in flight on the communication stream: (lo, hi, event) -- the sharded optimiser all-gathers
         # the updated masters bucket by bucket BEHIND the next forward, which waits per bucket (wait_range)
-        self.pending: List[Tuple[int, int, object]] = []
+        self.pending: List[Tuple[int, int, object, set]] = []
         self.master = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
         # bf16 mirror of the master buffer (same flat layout), written by the AdamW kernel: the forward operand of
@@ -189,26 +189,39 @@ class ParamStore:
     # ------------------------------------------------------------------ in-flight weight refreshes
     def wait_range(self, lo: int, hi: int) -> None:
         """Make the current stream wait for every in-flight refresh that touches flat[lo:hi] (no-op when nothing is pending:
-        the single-process and all-reduce paths never have anything)."""
+        the single-process and all-reduce paths never have anything).  Entries stay in ``pending`` until ``wait_all`` -- the
+        two towers may read parameters of one bucket from two different streams (net.py: towers side by side), and each of
+        those streams has to wait; an entry remembers the streams that already did."""
         if not self.pending:
             return
-        keep, hit = [], []
-        for plo, phi, ev in self.pending:
-            (hit if (plo < hi and lo < phi) else keep).append((plo, phi, ev))
-        self.pending = keep
+        hit, cur = [], None
+        for ent in self.pending:
+            plo, phi, ev, waited = ent
+            if plo < hi and lo < phi:
+                cur = cur or torch.cuda.current_stream(self.device)
+                if cur.cuda_stream not in waited:
+                    waited.add(cur.cuda_stream)
+                    hit.append(ev)
         if hit:
             from . import comm          # (bench.py's instrumented pass times this wait: comm.CommProbe)
-            cur = torch.cuda.current_stream(self.device)
             comm._stalled("weight refresh behind the forward (optimiser / all-gather)", self.device,
-                          lambda: [cur.wait_event(ev) for _, _, ev in hit])
+                          lambda: [cur.wait_event(ev) for ev in hit])
+
+    def add_pending(self, lo: int, hi: int, event) -> None:
+        """Register an update of flat[lo:hi] that is still running on another stream; ``event`` marks its end."""
+        self.pending.append((lo, hi, event, set()))
 
     def wait_names(self, names: List[str]) -> None:
         if self.pending:
             self.wait_range(*self.grad_range(names))
 
     def wait_all(self) -> None:
+        """The current stream waits for every in-flight update; the list is cleared (callers: the start of a backward, of an
+        optimiser step, state_dict / load_state_dict -- points behind which every stream of the step is ordered after the
+        current one)."""
         if self.pending:
             self.wait_range(0, self.total)
+            self.pending = []
 
     def grad_range(self, names: List[str]) -> Tuple[int, int]:
         lo = min(self.by_name[n].offset for n in names)

@@ -421,6 +421,8 @@ class TransformerStack:
         ov_env = os.environ.get("SC_OVERLAP", "auto")
         main = torch.cuda.current_stream()
         trial = None
+        if getattr(self, "no_side_stream", False):      # this stack runs beside the other tower on a stream of its own (net.py)
+            ov_env = "0"
         if ov_env in ("0", "1"):
             overlap = ov_env == "1"
         else:

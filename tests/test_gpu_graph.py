@@ -105,3 +105,42 @@ def test_graph_refuses_what_it_cannot_capture(monkeypatch):
     assert step.capturable() is None
     step(b)
     assert step.graph is not None and step.failed is None and step.replays == 1     # (the shape had run eagerly before)
+
+
+@pytest.mark.parametrize("second", ["text", "genetr"])
+def test_towers_side_by_side_give_the_bits_of_the_sequential_order(second, monkeypatch):
+    """net.py (round 6): the second tower on its own stream beside the vision tower -- same kernels on the same values, so
+    losses, gradients and the weights after optimiser steps are bit-identical to the sequential order (SC_TOWER_OVERLAP=0),
+    with the optimiser's update still running behind the forward on a third stream."""
+    data, graph, losses, mc, module, net, optim = _pkg()
+    text = second == "text"
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 64, 2, 32),
+                      text=mc.TextCfg(16, 97, 64, 2, 2) if text else None,
+                      gene=None if text else mc.GeneCfg(512, 64, kind="transformer", patch=64, width=64, layers=2, head_width=32))
+    B, steps = 24, 4
+    batches = []
+    for s in range(steps):
+        b = data.synthetic_batch(B, 32, 512, K=4, step=s)
+        if text:
+            b["texts"] = data.synthetic_captions(B, 16, 97, seed=s)
+        batches.append({k: v.cuda() for k, v in b.items()})
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SC_TOWER_OVERLAP", mode)
+        n, m, opt, sched = _build(cfg, "spatial")
+        ls = []
+        for i in range(steps):
+            loss = m.training_step(batches[i], i)
+            loss.backward(m.root_gradient(loss))
+            if i == 0:
+                g0 = n.store.grad.clone()
+            opt.step(grad_scale=1.0, max_norm=1.0)
+            sched.step()
+            ls.append(float(loss.detach()))
+        n.store.wait_all()
+        torch.cuda.synchronize()
+        assert getattr(n.second.stack, "no_side_stream", False) == (mode == "1")
+        res[mode] = (ls, g0, n.store.master.detach().clone(), opt.exp_avg.clone())
+    assert res["0"][0] == res["1"][0]
+    for k in (1, 2, 3):
+        assert torch.equal(res["0"][k], res["1"][k])
