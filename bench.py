@@ -501,9 +501,11 @@ def main():
         def instrumented(overlap):
             prev = os.environ.get("SC_OVERLAP")
             prev_b = os.environ.get("SC_ADAMW_BEHIND")
+            prev_t = os.environ.get("SC_TOWER_OVERLAP")
             os.environ["SC_OVERLAP"] = "1" if overlap else "0"
             if not overlap:                     # ... and nothing else beside a launch either: the optimiser as one launch in front
                 os.environ["SC_ADAMW_BEHIND"] = "0"      # of the forward instead of bucket by bucket behind it (read at every step)
+                os.environ["SC_TOWER_OVERLAP"] = "0"     # ... and the two towers one after the other (read at every forward / backward)
             for i in range(2):
                 step(args.warmup + args.steps + i, eager=True)
             fence()
@@ -522,6 +524,10 @@ def main():
                 os.environ.pop("SC_ADAMW_BEHIND", None)
             else:
                 os.environ["SC_ADAMW_BEHIND"] = prev_b
+            if prev_t is None:
+                os.environ.pop("SC_TOWER_OVERLAP", None)
+            else:
+                os.environ["SC_TOWER_OVERLAP"] = prev_t
             return ev, d
         events, dt_inst = instrumented(False)
         note(f"instrumented pass (single stream) done: {dt_inst / args.steps * 1e3:.2f} ms/step")
@@ -565,7 +571,7 @@ def main():
                     "avg_launch_us": round(sec / cnt * 1e6, 1), "flops_per_launch_avg": fl / cnt,
                     "share_of_step_time": round(sec / dt_inst, 3),
                     "measured_in": "extra pass over K steps with HIP events around every GEMM launch on its launch stream, "
-                                   "weight-gradient side stream OFF (SC_OVERLAP=0) and the optimiser as one launch (SC_ADAMW_BEHIND=0) so that a launch has the chip to itself",
+                                   "weight-gradient side stream OFF (SC_OVERLAP=0), the optimiser as one launch (SC_ADAMW_BEHIND=0) and the towers in sequence (SC_TOWER_OVERLAP=0) so that a launch has the chip to itself",
                     "instrumented_ms_per_step": round(dt_inst / args.steps * 1e3, 3)}
         if events_ov:
             ao = aggregate(events_ov)
