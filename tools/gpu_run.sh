@@ -36,10 +36,10 @@ for STEP in "$@"; do
     prof)
       MODE=${ARG%% *}; MODE=${MODE:-single}; EXTRA=""; [[ "$ARG" == *" "* ]] && EXTRA=${ARG#* }      # prof:single+--model+X ...: extra bench.py arguments
       D=$PWD/$OUT/prof_$MODE; rm -rf $D
-      # single: every kernel alone on the chip -- weight gradients on the chain stream AND the optimiser as one launch in front of the forward
-      if [ "$MODE" = single ]; then export SC_OVERLAP=0 SC_ADAMW_BEHIND=0; else unset SC_OVERLAP SC_ADAMW_BEHIND; fi
+      # single: every kernel alone on the chip -- weight gradients on the chain stream, the optimiser as one launch in front of the forward AND the two towers in sequence
+      if [ "$MODE" = single ]; then export SC_OVERLAP=0 SC_ADAMW_BEHIND=0 SC_TOWER_OVERLAP=0; else unset SC_OVERLAP SC_ADAMW_BEHIND SC_TOWER_OVERLAP; fi
       (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o s -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-events --no-loss-delta $EXTRA > $R/$OUT/prof_$MODE.log 2>&1)
-      unset SC_OVERLAP SC_ADAMW_BEHIND
+      unset SC_OVERLAP SC_ADAMW_BEHIND SC_TOWER_OVERLAP
       find $D -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_$MODE.csv" \;
       find $D -name '*kernel_trace.csv' -size +20M -delete
       head -30 "$OUT/kernel_stats_$MODE.csv" | cut -c1-200 ;;
