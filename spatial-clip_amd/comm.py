@@ -540,7 +540,11 @@ class GradBucketReducer:
                 self._launch(*self.pending)
                 self.pending = (lo, hi)
         plo, phi = self.pending
-        if phi - plo >= self.bucket_floats:
+        # Backward completes the flat buffer back to front, so what is announced LAST (the first blocks and the stem, offsets
+        # below one bucket) is the part of the exchange nothing is left to hide behind: it travels in quarter-size buckets, so
+        # that all but the last ~4 M floats are already on the wire when backward ends (the exposed tail of the all-reduce).
+        thresh = self.bucket_floats if plo >= self.bucket_floats else max(1, self.bucket_floats // 4)
+        if phi - plo >= thresh:
             self._launch(plo, phi)
             self.pending = None
 

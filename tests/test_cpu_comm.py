@@ -57,6 +57,16 @@ def _worker(rank, world, port, ret):
         red.bucket_ready(lo, hi)
     red.finish()
     out["flat"] = flat.numpy()
+    # the tail of the exchange (offsets below one bucket: what backward announces last) travels in quarter-size buckets
+    flat2 = torch.ones(4096, dtype=torch.float32)
+    red2 = comm.GradBucketReducer(flat2, bucket_floats=1024)
+    sizes = []
+    for lo in range(4096 - 128, -1, -128):
+        red2.bucket_ready(lo, lo + 128)
+        sizes = [hi - lo_ for lo_, hi in red2.launched]
+    assert sizes[:3] == [1024, 1024, 1024] and all(sz == 256 for sz in sizes[3:]) and len(sizes) == 3 + 4, sizes
+    red2.finish()
+    assert torch.equal(flat2, torch.full((4096,), float(world)))
     ret[rank] = out
     dist.destroy_process_group()
 
