@@ -144,3 +144,44 @@ def test_towers_side_by_side_give_the_bits_of_the_sequential_order(second, monke
     assert res["0"][0] == res["1"][0]
     for k in (1, 2, 3):
         assert torch.equal(res["0"][k], res["1"][k])
+
+
+def test_trainer_fit_with_the_graphed_step_equals_the_enqueued_fit(monkeypatch, tmp_path):
+    """Trainer.fit on the reference's pairing in miniature (vision tower + CLIP text tower, towers side by side), two epochs with
+    validation, a mid-run checkpoint and a ragged last batch: SC_GRAPH=1 (capture as soon as possible) and SC_GRAPH=0 end with
+    the same weights, Adam moments and validation record, bit for bit -- and the graph really ran."""
+    data, graph, losses, mc, module, net, optim = _pkg()
+    from spatial_clip_amd.trainer import Trainer
+    monkeypatch.setenv("SC_OVERLAP", "1")
+    cfg = mc.ModelCfg(embed_dim=64, vision=mc.VisionCfg(32, 8, 64, 2, 32), text=mc.TextCfg(16, 97, 64, 2, 2), gene=None)
+
+    class TextDM(data.SyntheticSpatialDataModule):
+        def _loader(self, n, offset):
+            for s in range(n):
+                B = self.batch_size if s + 1 < n else self.batch_size - 5           # ragged last batch of the epoch
+                b = data.synthetic_batch(B, self.image_size, 64, self.k_neighbors, offset + s)
+                b["texts"] = data.synthetic_captions(B, 16, 97, seed=offset + s)
+                yield b
+
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SC_GRAPH", mode)
+        n = net.SpatialClipNet("custom", None, model_cfg=cfg, seed=5)
+        m = module.SpatialClipLitModule(
+            n, losses.SpatialLoss(local_loss=True, gather_with_grad=True, cap_logit_scale=40.0, temp_reg_weight=0.05,
+                                  neighbor_alpha_scale=0.5, float32_logits=True),
+            functools.partial(optim.FusedAdamW, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.1),
+            functools.partial(optim.get_cosine_schedule_with_warmup, num_warmup_steps=2))
+        dm = TextDM(batch_size=16, image_size=32, n_genes=64, k_neighbors=4, steps_per_epoch=6, val_steps=2)
+        tr = Trainer(max_epochs=2, enable_checkpointing=True, default_root_dir=str(tmp_path / mode), log_every_n_steps=1)
+        tr.fit(m, dm)
+        torch.cuda.synchronize()
+        gs = tr.graphed_step
+        res[mode] = dict(w=n.store.master.detach().clone(), m=tr.optimizer.exp_avg.clone(), hist=[
+            {k: v for k, v in h.items() if k != "time_s"} for h in tr.history], replays=0 if gs is None else gs.replays,
+            failed=None if gs is None else gs.failed, side=getattr(n.second.stack, "no_side_stream", False))
+    assert res["0"]["replays"] == 0 and res["1"]["failed"] is None
+    assert res["1"]["replays"] == 2 * 5 - 1          # every full-size batch but the first (it warms the shape); the ragged ones run eagerly
+    assert res["0"]["side"] and res["1"]["side"]     # towers side by side in both runs
+    assert res["0"]["hist"] == res["1"]["hist"], (res["0"]["hist"], res["1"]["hist"])
+    assert torch.equal(res["0"]["w"], res["1"]["w"]) and torch.equal(res["0"]["m"], res["1"]["m"])
