@@ -67,6 +67,7 @@ class GraphedTrainStep:
         self.rows = 0
         self.replays = 0
         self.failed: Optional[str] = None
+        self._capture_stream = None
 
     # ------------------------------------------------------------------ preconditions
     def capturable(self) -> Optional[str]:
@@ -134,7 +135,9 @@ class GraphedTrainStep:
         totals = (m.train_metrics.total,)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        pool_stream = torch.cuda.Stream(priority=-1)
+        # the capture stream stays alive with the graph: scratch buffers are keyed by stream handle (ops.workspace), and a
+        # destroyed stream's handle could be handed to a later stream
+        pool_stream = self._capture_stream = torch.cuda.Stream(priority=-1)
         pool_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.graph(g, stream=pool_stream, capture_error_mode=os.environ.get("SC_GRAPH_CAPTURE_MODE", "thread_local")):
             loss = m.training_step({**self.static, **self.extra}, 0)
