@@ -71,18 +71,28 @@ class SyntheticSpatialDataModule:
         self.preprocess_fn = None
         self.tokenizer = None
         self._rates = None
+        self._text_cfg = None       # TextCfg of the net behind ``tokenizer`` when its second tower is the reference's CLIP text tower
 
     def setup(self, stage: Optional[str] = None) -> None:
         if self.preprocess_fn is None or self.tokenizer is None:       # spatial_datamodule.py:79-80
             raise ValueError("preprocess_fn and tokenizer must be set before setup()")
         self._rates = make_gene_rates(self.n_genes)
+        # The ``texts`` slot follows the model's second tower, as the reference's datamodule does by calling the model's own
+        # tokenizer (spatial_datamodule.py:79-80,120): BPE-shaped token ids [B, context_length] for the reference's CLIP text
+        # tower (model_name ViT-B-32 / ViT-B-16 / ...: configs/model/spatial_clip.yaml:10), the gene matrix for the gene towers.
+        net = getattr(self.tokenizer, "__self__", None)
+        self._text_cfg = getattr(getattr(net, "cfg", None), "text", None)
 
     def _loader(self, n: int, offset: int) -> Iterator[Dict[str, torch.Tensor]]:
         import torch.distributed as dist
         rank, W = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+        t = self._text_cfg
         for s in range(n):
-            yield synthetic_batch(self.batch_size, self.image_size, self.n_genes, self.k_neighbors, offset + s, rank, W,
-                                  self._rates)
+            b = synthetic_batch(self.batch_size, self.image_size, self.n_genes if t is None else 64, self.k_neighbors, offset + s,
+                                rank, W, self._rates if t is None else None)
+            if t is not None:
+                b["texts"] = synthetic_captions(self.batch_size, t.context_length, t.vocab_size, seed=4321 + 1000 * (offset + s) + rank)
+            yield b
 
     def set_epoch(self, epoch: int) -> None:
         """Trainer.fit calls this before every epoch: each epoch draws new synthetic batches (seed offset)."""
