@@ -196,7 +196,7 @@ def test_train_entry_reference_pairing_vitb32_text_tower(monkeypatch, tmp_path):
     monkeypatch.delenv("SC_OVERLAP", raising=False)
     import spatial_clip_amd  # noqa: F401
     from spatial_clip_amd import hydra_lite, train
-    cfg = hydra_lite.compose("train.yaml", ["experiment=vitb32_text_b32", "data.steps_per_epoch=40", "data.val_steps=1"])
+    cfg = hydra_lite.compose("train.yaml", ["experiment=vitb32_text_b32", "data.steps_per_epoch=40", "data.val_steps=1", "trainer.log_every_n_steps=10"])
     metrics, objects = train.train(cfg)
     net_ = objects["model"].net
     assert net_.cfg.text is not None and net_.cfg.text.vocab_size == 49408 and net_.cfg.vision.patch_size == 32
