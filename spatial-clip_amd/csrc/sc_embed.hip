@@ -455,16 +455,24 @@ __global__ __launch_bounds__(64) void token_embed_bwd_det_kernel(const long long
     flush();
 }
 
-__global__ void argmax_rows_kernel(const long long* __restrict__ tokens, int* __restrict__ out, int B, int L) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per row: lanes take tokens lane, lane + 64, ...; first maximum (smallest index among equal values), like torch.argmax
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const long long* __restrict__ tokens, int* __restrict__ out, int B, int L) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    long long best = tokens[(long long)b * L];
-    int bi = 0;
-    for (int t = 1; t < L; ++t) {
+    long long best = tokens[(long long)b * L + (lane < L ? lane : 0)];
+    int bi = lane < L ? lane : 0;
+    for (int t = lane + 64; t < L; t += 64) {
         const long long v = tokens[(long long)b * L + t];
-        if (v > best) { best = v; bi = t; }      // first maximum, like torch.argmax
+        if (v > best) { best = v; bi = t; }
     }
-    out[b] = bi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) out[b] = bi;
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int L,
@@ -537,7 +545,7 @@ extern "C" int sc_token_embed_bwd_det(const long long* tokens, const int* eot, c
 
 extern "C" int sc_argmax_rows_i64(const long long* tokens, int* out_idx, int B, int L, void* stream) {
     SC_CHECK(B > 0 && L > 0, "sc_argmax_rows_i64: bad shape");
-    argmax_rows_kernel<<<(B + 255) / 256, 256, 0, (hipStream_t)stream>>>(tokens, out_idx, B, L);
+    argmax_rows_kernel<<<(B + 3) / 4, 256, 0, (hipStream_t)stream>>>(tokens, out_idx, B, L);
     SC_LAUNCH_CHECK();
     return 0;
 }

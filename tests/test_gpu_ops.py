@@ -622,3 +622,18 @@ def test_token_embedding_backward_is_deterministic_and_matches_index_add(B, L, d
     dn = torch.empty(V, d, device="cuda")
     ops.token_embed_bwd(tokens, dres, dn, dp, B, L, d, V, eot=None, deterministic=True)
     assert torch.equal(dn, outs[0])
+
+
+@pytest.mark.parametrize("B,L", [(1, 1), (5, 16), (64, 77), (33, 130), (256, 77)])
+def test_argmax_rows_first_maximum_like_torch(B, L):
+    """EOT pooling position = text.argmax(-1) (src/open_clip/transformer.py:931-934): first maximum, rows with repeated maxima,
+    maxima at either end, more tokens than lanes."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    tokens = torch.randint(0, 50, (B, L), generator=g, dtype=torch.int64)       # small range: many ties
+    if L > 1:
+        tokens[0, -1] = 10_000
+        tokens[min(1, B - 1), 0] = 20_000
+    out = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    ops.argmax_rows(tokens.cuda(), out, B, L)
+    assert torch.equal(out.cpu().long(), tokens.argmax(dim=-1))
