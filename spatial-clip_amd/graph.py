@@ -89,9 +89,12 @@ class GraphedTrainStep:
         return None
 
     # ------------------------------------------------------------------ the two forms of the step
-    def eager(self, batch: Dict[str, Any]) -> torch.Tensor:
+    def eager(self, batch: Dict[str, Any], probe: bool = False) -> torch.Tensor:
+        """The enqueued step.  ``probe`` (set by ``__call__`` once the step could be captured, i.e. in steady state: the first
+        steps of a process load code objects and run the schedule trials, their device times say nothing): time the host
+        enqueue and, with two events, the device side of this step for the host-bound test."""
         import time
-        probe = self.policy == "host_bound" and self.graph is None and len(self._host_ms) < 8
+        probe = probe and self.policy == "host_bound" and self.graph is None and len(self._host_ms) < 8
         if probe:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -156,7 +159,7 @@ class GraphedTrainStep:
                 return self.eager(batch)
             worth = self.worthwhile()
             if worth is None:
-                return self.eager(batch)
+                return self.eager(batch, probe=True)
             if not worth:
                 self.failed = "not captured: the eager step is GPU-bound (host enqueue below %.0f %% of the device time)" % (100 * self.HOST_BOUND_RATIO)
                 return self.eager(batch)
