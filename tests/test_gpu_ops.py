@@ -617,7 +617,8 @@ def test_token_embedding_backward_is_deterministic_and_matches_index_add(B, L, d
     torch.testing.assert_close(dp, dres.view(B, L, d).sum(0), rtol=1e-5, atol=1e-5)
     da = torch.empty(V, d, device="cuda")
     ops.token_embed_bwd(tokens, dres, da, dp, B, L, d, V, deterministic=False)
-    torch.testing.assert_close(da, outs[0], rtol=1e-5, atol=1e-5)
+    # (the atomic kernel's own summation order changes from run to run: up to 256 fp32 additions of O(1) values per element)
+    torch.testing.assert_close(da, outs[0], rtol=1e-4, atol=2e-4)
     # without the pooled positions every row is visited: same result (the skipped rows were zeros)
     dn = torch.empty(V, d, device="cuda")
     ops.token_embed_bwd(tokens, dres, dn, dp, B, L, d, V, eot=None, deterministic=True)
