@@ -586,7 +586,7 @@ def test_cast_transpose_batched_from_master_and_from_mirror():
             off += r * c
 
 
-@pytest.mark.parametrize("B,L,d,V", [(64, 77, 512, 49408), (5, 16, 64, 97), (256, 77, 512, 49408)])
+@pytest.mark.parametrize("B,L,d,V", [(64, 77, 512, 49408), (5, 16, 64, 97), (256, 77, 512, 49408), (512, 77, 64, 1000)])      # (the last: two LDS segments)
 def test_token_embedding_backward_is_deterministic_and_matches_index_add(B, L, d, V):
     """sc_token_embed_bwd_det (round 6): the scatter-add of the embedding gather without float atomics -- equal to an fp64
     index_add within fp32 rounding, equal to the atomic kernel within rounding, BIT-identical from launch to launch, rows of
